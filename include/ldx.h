@@ -1,0 +1,122 @@
+/* ldx.h — C ABI of libldx.so, the MI355X-native drop-in for LightDiffusion-Next's denoising hot path.
+ *
+ * The reference (Aatricks/LightDiffusion-Next, 100 % Python) exposes one plugin boundary for an
+ * accelerated UNet: model_options["model_function_wrapper"], called at src/cond/cond.py:254-263 as
+ *     wrapper(model.apply_model, {"input", "timestep", "c", "cond_or_uncond"})
+ * and installed with ModelPatcher.set_model_unet_function_wrapper (src/Model/ModelPatcher.py:138-144);
+ * Stable-Fast (src/StableFast/StableFast.py:230-274) and FBCache (src/WaveSpeed/fbcache_nodes.py:96-111)
+ * sit behind it.  Everything below is what a ctypes binding for that hook needs: plain pointers and
+ * sizes, no torch types.  All `const float*` / `void*` tensor arguments of the compute calls are
+ * DEVICE pointers on the engine's device; ldx_load_tensor takes HOST pointers.
+ *
+ * Conventions: every call returns 0 on success or a negative LDX_E* code; ldx_last_error() returns a
+ * thread-local human-readable message.  One engine per device, not thread-safe (the reference has a
+ * single caller thread).  `stream` is a hipStream_t passed as void* (NULL = default).
+ */
+#ifndef LDX_H
+#define LDX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDX_OK 0
+#define LDX_EINVAL (-1)      /* bad argument / unsupported configuration */
+#define LDX_EMISSING (-2)    /* a required weight tensor was not loaded */
+#define LDX_EHIP (-3)        /* HIP runtime error */
+#define LDX_ESTATE (-4)      /* call sequence error (e.g. denoise before finalize) */
+
+/* element types */
+#define LDX_BF16 0
+#define LDX_F16 1
+#define LDX_F32 2
+
+typedef struct ldx_engine ldx_engine;
+
+/* Mirrors the keyword arguments of UNetModel1.__init__ (src/NeuralNetwork/unet.py:208-252) that the
+ * SD1.5 family uses (src/SD15/SD15.py:10-77 + detect_unet_config unet.py:773-1080). */
+typedef struct ldx_unet_config {
+    int32_t compute_dtype;              /* LDX_BF16 (default) or LDX_F16: activation + weight storage type */
+    int32_t in_channels;                /* 4 */
+    int32_t out_channels;               /* 4 */
+    int32_t model_channels;             /* 320; must be a multiple of 64 */
+    int32_t num_levels;                 /* len(channel_mult) = 4 */
+    int32_t channel_mult[8];            /* 1,2,4,4 */
+    int32_t num_res_blocks[8];          /* 2,2,2,2 */
+    int32_t transformer_depth[32];      /* per input res block, consumed front-to-back: 1,1,1,1,1,1,0,0 */
+    int32_t transformer_depth_output[48]; /* per output block, stored in the reference's order (popped from the END) */
+    int32_t transformer_depth_middle;   /* 1 ; -1 = no transformer, -2 = no middle block */
+    int32_t num_heads;                  /* 8 */
+    int32_t context_dim;                /* 768; multiple of 64 */
+} ldx_unet_config;
+
+/* ---- lifecycle -------------------------------------------------------------------------------- */
+const char* ldx_version(void);
+const char* ldx_last_error(void);
+/* Create an engine for `device` (HIP ordinal).  Replaces BaseModel.__init__ + UNetModel1.__init__
+ * (src/Model/ModelBase.py:38-57, unet.py:208-677) for the accelerated path. */
+int ldx_create(const ldx_unet_config* cfg, int device, ldx_engine** out);
+void ldx_destroy(ldx_engine* e);
+/* Hand one state-dict tensor to the engine (HOST pointer; dtype LDX_F16|LDX_BF16|LDX_F32).  Keys use
+ * the SD1.5 `model.diffusion_model.` layout with that prefix stripped, e.g.
+ * "input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight".  Replaces BaseModel.load_model_weights
+ * (ModelBase.py:178-202) + the per-forward cast of cond/cast.py:44-78 (cast happens once, here). */
+int ldx_load_tensor(ldx_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+/* Sigma / timestep tables built by the host exactly as the reference builds them
+ * (ModelSamplingDiscrete.set_sigmas sampling.py:285-289 -> log_sigmas[n];
+ *  timestep_embedding sampling_util.py:56-76 evaluated at t = 0..n-1 -> temb[n][model_channels]). */
+int ldx_set_tables(ldx_engine* e, const float* log_sigmas, int n, const float* temb, int temb_dim);
+/* Pack weights into MFMA-friendly layouts and upload them.  After this the host copies are dropped. */
+int ldx_finalize(ldx_engine* e);
+
+/* ---- the hot path ----------------------------------------------------------------------------- */
+/* The wrapper body: denoised = x - UNet(x / sqrt(sigma^2+1), t(sigma), ctx) * sigma — i.e. all of
+ * BaseModel.apply_model (ModelBase.py:72-133) for EPS prediction (sampling.py:26-56).
+ *   x_nchw  [B2][C][h][w] fp32, sigma [B2] fp32 (sigma VALUES, as the hook passes them),
+ *   ctx     [B2][M][context_dim] fp32 (c["c_crossattn"]), out_nchw like x_nchw.  */
+int ldx_unet_denoise(ldx_engine* e, const float* x_nchw, const float* sigma, const float* ctx,
+                     int B2, int h, int w, int M, float* out_nchw, void* stream);
+/* Raw UNetModel1.forward (unet.py:679-770): x (already scaled), integer timesteps given as fp32. */
+int ldx_unet_forward(ldx_engine* e, const float* x_nchw, const float* timesteps, const float* ctx,
+                     int B2, int h, int w, int M, float* out_nchw, void* stream);
+/* Number of kernel launches in the current plan, algorithmic FLOPs of one forward at the planned shape
+ * (2*MACs of every Linear/Conv + 4*B*H*N*M*D per attention), arena bytes. */
+int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes);
+/* Capture the planned forward into a hipGraph for replay (0 = eager launches). */
+int ldx_set_graph_mode(ldx_engine* e, int enable);
+
+/* ---- sampler-side elementwise ops (src/sample/samplers.py, src/sample/CFG.py) ------------------ */
+/* d = lerp(den_uncond, den_cond, cfg) (CFG.py:60), then
+ * kind 0: Euler  x = x + ((x - d)/c0)*c1, c0 = sigma_hat, c1 = sigma_next - sigma_hat (samplers.py:308; util.py:26-37)
+ * kind 1: DPM++ first order  x = c0*x - c1*d, c0 = sigma_next/sigma, c1 = expm1(-h)   (samplers.py:945-946)
+ * kind 2: CFG combine only (denoised_out = d; x untouched) — low-resolution multiscale steps.
+ * Same fp32 operation order as the reference expressions, no FMA contraction.  denoised_out may be NULL. */
+int ldx_sampler_step(int kind, float* x, const float* den_uncond, const float* den_cond, float* denoised_out,
+                     int64_t n, float cfg, float c0, float c1, void* stream);
+/* F.interpolate(mode="bilinear", align_corners=False) on fp32 [planes][H][W] (samplers.py:227-241). */
+int ldx_bilinear(const float* in, float* out, int planes, int hin, int win, int hout, int wout, void* stream);
+
+/* ---- single-op entry points (parity tests call the kernels through these) ----------------------- */
+/* 16-bit tensors are device pointers to bf16/fp16 per `dtype`.  Layouts: see csrc/ldx_kernels.h. */
+int ldx_op_convert(const float* in_f32, void* out_16, int64_t n, int dtype, int to_f32, void* stream);
+int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias,
+                const float* rowvec, int rowvec_ld, int rows_per_batch, int geglu,
+                const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream);
+int ldx_op_conv3x3(const void* X, int ldx, const void* W, int B, int Hin, int Win, int Cin, int Cout,
+                   int stride, int Hout, int Wout, int resize_to_out, const float* bias,
+                   const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,
+                   int dtype, void* stream);
+int ldx_op_groupnorm(const void* X, int ldx, void* Y, int ldy, int B, int HW, int C, int G, float eps, int silu,
+                     const float* gamma, const float* beta, float* workspace, int dtype, void* stream);
+int64_t ldx_op_groupnorm_workspace_floats(int B, int G);
+int ldx_op_layernorm(const void* X, int ldx, void* Y, int ldy, int rows, int C, float eps,
+                     const float* gamma, const float* beta, int dtype, void* stream);
+int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                     int B, int H, int Nq, int Mk, int D, float scale, int causal, int dtype, void* stream);
+int ldx_op_skinny(const float* x, int ldx, const void* W, const float* bias, float* out, int ldo,
+                  int M, int N, int K, int in_act, int out_act, int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDX_H */

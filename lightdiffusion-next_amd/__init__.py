@@ -1,0 +1,17 @@
+"""ldx — MI355X-native engine for LightDiffusion-Next's denoising hot path.
+
+The package directory is named ``lightdiffusion-next_amd`` (not a Python identifier); import it as
+``import ldx_amd`` (shim at the repository root) or ``importlib.import_module("lightdiffusion-next_amd")``.
+
+Layout:
+  csrc/        hand-written HIP kernels for gfx950 + the C ABI (include/ldx.h) -> libldx.so
+  lib.py       ctypes binding of libldx.so (fails loudly if the library or a GPU is missing)
+  engine.py    UNetEngine: weights in, denoise out (device pointers through the C ABI)
+  hook.py      LdxUNetPatch: drop-in for model_options["model_function_wrapper"] (cond.py:254-263)
+  sampling.py  host mirror of src/sample (schedulers, CFG batching, Euler / DPM++ loops)
+  weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
+"""
+from . import lib, weights  # noqa: F401
+from .engine import UNetEngine, UNetConfig  # noqa: F401
+from .hook import LdxUNetPatch  # noqa: F401
+from . import sampling  # noqa: F401

@@ -1,0 +1,265 @@
+// Flash attention (online softmax) for gfx950 — replaces the reference's
+// Attention.optimized_attention -> F.scaled_dot_product_attention call sites
+// (Attention/AttentionMethods.py:107-150, used by CrossAttention.forward Attention.py:100-124;
+// CLIP: clip/Clip.py:14-60 with a causal mask).
+//
+// Formulation (everything "transposed" so per-query statistics stay lane-local):
+//   S^T[kv][q] = K[kv][:] . Q[q][:]          mfma(a = K frag, b = Q frag)
+//   P          = exp2(S*c - m*c)             fp32 online softmax, c = scale*log2(e)
+//   O^T[d][q] += V^T[d][kv] * P^T[kv][q]     mfma(a = V^T frag, b = P frag)
+// With the 16x16x32 MFMA result layout (col = lane&15, rows = 4*(lane>>4)+r) the query index of
+// every accumulator in both S^T and O^T is lane&15, so running max / rescale / denominator need
+// no cross-lane traffic except one 4-lane max per 64-key block.  The k-slot <-> key permutation
+// induced by feeding S^T accumulators straight back as the P operand is absorbed by reading the
+// V^T fragment as two 8-byte pieces (keys 4g..4g+3 of two 16-key tiles).
+//
+// Workgroup = 4 waves x 32 queries; K and V^T tiles of 64 keys double-buffered in LDS, global
+// loads register-staged one block ahead.  Head dims D in {8..160}, D % 8 == 0: the QK^T
+// contraction is padded to 32*KS, the PV output to 16*DT rows (zero-filled in LDS/registers).
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+constexpr int AT_KV = 64;         // keys per block
+constexpr int AT_QW = 32;         // queries per wave
+constexpr int AT_QB = 128;        // queries per workgroup
+constexpr int VT_ROWB = AT_KV * 2 + 16;   // V^T LDS row bytes (64 keys + 16 B pad)
+
+template <int KS> struct AttnCfg { static constexpr int KROWB = KS * 64 + 16; };  // K LDS row bytes (padded)
+
+template <typename T, int KS, int DT>
+__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V8 = typename Vec<T>::v8;
+    constexpr int KROWB = AttnCfg<KS>::KROWB;
+    constexpr int KBYTES = AT_KV * KROWB;
+    constexpr int VBYTES = DT * 16 * VT_ROWB;
+    constexpr int STAGE = KBYTES + VBYTES;
+    constexpr int MAXCH = (KS * 4 > DT * 2) ? KS * 4 : DT * 2;     // upper bound on D/8
+    constexpr int NLD = (AT_KV * MAXCH + 255) / 256;                // staging chunks per thread
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l15 = lane & 15, g4 = lane >> 4;
+    const int h = blockIdx.y, b = blockIdx.z;
+    const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
+    const int D = p.D, dch = D >> 3;           // 16-B chunks per head row
+    const T* __restrict__ Qp = (const T*)p.Q + (long)b * p.Nq * p.ldq + h * D;
+    const T* __restrict__ Kp = (const T*)p.K + (long)b * p.Mk * p.ldk + h * D;
+    const T* __restrict__ Vp = (const T*)p.V + (long)b * p.Mk * p.ldv + h * D;
+    T* __restrict__ Op = (T*)p.O + (long)b * p.Nq * p.ldo + h * D;
+    const float c = p.scale * 1.44269504088896340736f;
+
+    // zero both LDS stages once: K pad columns (d >= D) and V^T pad rows must read as 0.
+    for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+
+    // Q fragments (B operand): lane holds q = l15, d = ks*32 + g4*8 .. +7
+    V8 qf[2][KS];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 16 + l15;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const int ch = ks * 4 + g4;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            qf[qt][ks] = as_v8<T>(u);
+        }
+    }
+
+    f32x4 o[2][DT];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    float mrun[2] = {-INFINITY, -INFINITY};
+    float lrun[2] = {0.f, 0.f};
+
+    // number of key blocks this workgroup needs (causal: keys <= last query of the block)
+    int mk_eff = p.Mk;
+    if (p.causal) mk_eff = min(p.Mk, blockIdx.x * AT_QB + AT_QB);
+    const int nblk = (mk_eff + AT_KV - 1) / AT_KV;
+
+    uint4 rk[NLD], rv[NLD];
+    auto gload = [&](int blk) {
+        const int kv0 = blk * AT_KV;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / dch, ch = idx - row * dch;
+            const int kv = kv0 + row;
+            const bool ok = row < AT_KV && kv < p.Mk;
+            rk[i] = ok ? *(const uint4*)(Kp + (long)kv * p.ldk + ch * 8) : make_uint4(0, 0, 0, 0);
+            rv[i] = ok ? *(const uint4*)(Vp + (long)kv * p.ldv + ch * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* sK = smem + stage * STAGE;
+        char* sV = sK + KBYTES;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const int idx = tid + i * 256;
+            const int row = idx / dch, ch = idx - row * dch;
+            if (row < AT_KV) {
+                *(uint4*)(sK + row * KROWB + ch * 16) = rk[i];
+                // transpose V[kv=row][d = ch*8+e] -> V^T[d][kv]
+                union { uint4 u; unsigned short s[8]; } x; x.u = rv[i];
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    *(unsigned short*)(sV + (ch * 8 + e) * VT_ROWB + row * 2) = x.s[e];
+            }
+        }
+    };
+
+    __syncthreads();      // zero-fill visible before first tile lands
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        const bool more = (blk + 1) < nblk;
+        if (more) gload(blk + 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + KBYTES;
+        const int kv0 = blk * AT_KV;
+
+        // ---- S^T = K Q^T : 4 key tiles x 2 query tiles ----
+        f32x4 s[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const V8 kf = as_v8<T>(*(const uint4*)(sK + (t * 16 + l15) * KROWB + (ks * 4 + g4) * 16));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[qt][t] = mfma16(kf, qf[qt][ks], s[qt][t]);
+            }
+        }
+
+        // ---- masking (block-uniform fast path) ----
+        const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > blockIdx.x * AT_QB));
+        if (need_mask) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                const int q = q0 + qt * 16 + l15;
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int kv = kv0 + t * 16 + g4 * 4 + r;
+                        const bool dead = kv >= p.Mk || (p.causal && kv > q);
+                        if (dead) s[qt][t][r] = -INFINITY;
+                    }
+            }
+        }
+
+        // ---- online softmax; P packed as B-operand fragments ----
+        V8 pf[2][2];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = s[qt][0][0];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][t][r]);
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float mnew = fmaxf(mrun[qt], mx);
+            // rows with every key masked so far keep mnew = -inf; guard the (-inf) - (-inf) case
+            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] * c - mc);
+            mrun[qt] = mnew;
+            float psum = 0.f;
+            float pv[4][4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][t][r], c, -mc));
+                    pv[t][r] = e;
+                    psum += e;
+                }
+            lrun[qt] = lrun[qt] * alpha + psum;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
+            }
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                V8 f;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { f[r] = (T)pv[2 * ks2][r]; f[4 + r] = (T)pv[2 * ks2 + 1][r]; }
+                pf[qt][ks2] = f;
+            }
+        }
+
+        // ---- O^T += V^T P^T ----
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+#pragma unroll
+            for (int ks2 = 0; ks2 < 2; ++ks2) {
+                const char* vrow = sV + (dt * 16 + l15) * VT_ROWB;
+                U128 vf;
+                vf.d[0] = *(const uint2*)(vrow + (ks2 * 32 + g4 * 4) * 2);
+                vf.d[1] = *(const uint2*)(vrow + (ks2 * 32 + 16 + g4 * 4) * 2);
+                const V8 v8 = as_v8<T>(vf.u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma16(v8, pf[qt][ks2], o[qt][dt]);
+            }
+        }
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finalize: O = O^T / l ; lane holds q = l15, d = dt*16 + 4*g4 + r ----
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        float l = lrun[qt];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+        const int q = q0 + qt * 16 + l15;
+        if (q >= p.Nq) continue;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const int d = dt * 16 + g4 * 4;
+            if (d < D)
+                *(uint2*)(Op + (long)q * p.ldo + d) =
+                    pack4<T>(o[qt][dt][0] * inv, o[qt][dt][1] * inv, o[qt][dt][2] * inv, o[qt][dt][3] * inv);
+        }
+    }
+}
+
+template <typename T, int KS, int DT>
+static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    constexpr int STAGE = AT_KV * AttnCfg<KS>::KROWB + DT * 16 * VT_ROWB;
+    const size_t lds = 2 * STAGE;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_kernel<T, KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    dim3 grid((a.Nq + AT_QB - 1) / AT_QB, a.H, a.B);
+    hipLaunchKernelGGL((attn_kernel<T, KS, DT>), grid, dim3(256), lds, s, a);
+}
+
+template <typename T>
+static void launch_attn_d(const AttnArgs& a, hipStream_t s) {
+    const int D = a.D;
+    if (D <= 16) launch_attn_t<T, 1, 1>(a, s);
+    else if (D <= 32) launch_attn_t<T, 1, 2>(a, s);
+    else if (D <= 48) launch_attn_t<T, 2, 3>(a, s);
+    else if (D <= 64) launch_attn_t<T, 2, 4>(a, s);
+    else if (D <= 80) launch_attn_t<T, 3, 5>(a, s);
+    else if (D <= 96) launch_attn_t<T, 3, 6>(a, s);
+    else if (D <= 128) launch_attn_t<T, 4, 8>(a, s);
+    else launch_attn_t<T, 5, 10>(a, s);
+}
+
+void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {
+    if (a.Nq <= 0 || a.B <= 0) return;
+    if (dt == DT_BF16) launch_attn_d<__bf16>(a, s); else launch_attn_d<_Float16>(a, s);
+}
+
+}  // namespace ldx

@@ -1,0 +1,161 @@
+// extern "C" surface of libldx.so (include/ldx.h).  No exceptions cross the ABI.
+#include <new>
+
+#include "engine.h"
+
+using namespace ldx;
+
+struct ldx_engine { Engine* impl; };
+
+#define GUARD_BEGIN try {
+#define GUARD_END                                                                  \
+    }                                                                              \
+    catch (const std::bad_alloc&) { set_error("out of host memory"); return LDX_EINVAL; } \
+    catch (const std::exception& ex) { set_error(std::string("internal error: ") + ex.what()); return LDX_EINVAL; }
+
+static int check_device(int device) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { set_error("no HIP device available (libldx has no CPU fallback)"); return LDX_EHIP; }
+    if (device < 0 || device >= n) { set_error("device ordinal out of range"); return LDX_EINVAL; }
+    return LDX_OK;
+}
+static inline DType dtype_of(int d) { return d == LDX_F16 ? DT_F16 : DT_BF16; }
+static int check_launch(const char* what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string(what) + ": " + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+extern "C" {
+
+const char* ldx_version(void) { return "ldx 0.1 (gfx950)"; }
+const char* ldx_last_error(void) { return g_last_error.c_str(); }
+
+int ldx_create(const ldx_unet_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    Engine* e = new Engine(*cfg, device);
+    rc = e->validate();
+    if (rc) { delete e; return rc; }
+    *out = new ldx_engine{e};
+    return LDX_OK;
+    GUARD_END
+}
+void ldx_destroy(ldx_engine* e) { if (e) { delete e->impl; delete e; } }
+
+int ldx_load_tensor(ldx_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->load_tensor(key, data, dtype, shape, ndim);
+    GUARD_END
+}
+int ldx_set_tables(ldx_engine* e, const float* log_sigmas, int n, const float* temb, int temb_dim) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->set_tables(log_sigmas, n, temb, temb_dim);
+    GUARD_END
+}
+int ldx_finalize(ldx_engine* e) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->finalize();
+    GUARD_END
+}
+int ldx_unet_denoise(ldx_engine* e, const float* x, const float* sigma, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream);
+    GUARD_END
+}
+int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run(x, t, ctx, B2, h, w, M, out, false, (hipStream_t)stream);
+    GUARD_END
+}
+int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (n_launches) *n_launches = e->impl->n_launches();
+    if (flops) *flops = e->impl->flops;
+    if (arena_bytes) *arena_bytes = (int64_t)e->impl->arena_cap;
+    return LDX_OK;
+}
+int ldx_set_graph_mode(ldx_engine* e, int enable) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    e->impl->graph_mode = enable != 0;
+    return LDX_OK;
+}
+
+int ldx_sampler_step(int kind, float* x, const float* du, const float* dc, float* dout, int64_t n, float cfg, float c0, float c1, void* stream) {
+    if (!x || !du || !dc || n < 0 || (kind < 0 || kind > 2)) { set_error("ldx_sampler_step: bad argument"); return LDX_EINVAL; }
+    StepArgs a{x, du, dc, dout, (size_t)n, cfg, kind, c0, c1};
+    launch_sampler_step(a, (hipStream_t)stream);
+    return check_launch("ldx_sampler_step");
+}
+int ldx_bilinear(const float* in, float* out, int planes, int hin, int win, int hout, int wout, void* stream) {
+    if (!in || !out || planes <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) { set_error("ldx_bilinear: bad argument"); return LDX_EINVAL; }
+    launch_bilinear(in, out, planes, hin, win, hout, wout, (hipStream_t)stream);
+    return check_launch("ldx_bilinear");
+}
+
+int ldx_op_convert(const float* in_f32, void* out_16, int64_t n, int dtype, int to_f32, void* stream) {
+    if (!in_f32 || !out_16 || n < 0) { set_error("ldx_op_convert: bad argument"); return LDX_EINVAL; }
+    if (to_f32) launch_t_to_f32(out_16, (float*)in_f32, (size_t)n, dtype_of(dtype), (hipStream_t)stream);
+    else launch_f32_to_t(in_f32, out_16, (size_t)n, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_convert");
+}
+int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* rowvec, int rowvec_ld,
+                int rows_per_batch, int geglu, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream) {
+    if (!A || !W || M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || (!C && !Cf)) { set_error("ldx_op_gemm: bad argument (K % 64, lda % 8)"); return LDX_EINVAL; }
+    GemmArgs g{};
+    g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.mode = 0; g.bias = bias;
+    g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.geglu = geglu;
+    g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cf = Cf; g.ldcf = ldcf;
+    launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_gemm");
+}
+int ldx_op_conv3x3(const void* X, int ldx_, const void* W, int B, int Hin, int Win, int Cin, int Cout, int stride, int Hout, int Wout,
+                   int resize_to_out, const float* bias, const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,
+                   int dtype, void* stream) {
+    if (!X || !W || !Y || Cin % 64 || ldx_ % 8 || (stride != 1 && stride != 2)) { set_error("ldx_op_conv3x3: bad argument (Cin % 64)"); return LDX_EINVAL; }
+    GemmArgs g{};
+    g.A = X; g.lda = ldx_; g.W = W; g.M = B * Hout * Wout; g.N = Cout; g.K = 9 * Cin; g.mode = 1;
+    g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = stride;
+    if (resize_to_out) { g.Hv = Hout; g.Wv = Wout; } else { g.Hv = Hin; g.Wv = Win; }
+    g.resize = (g.Hv != Hin || g.Wv != Win) ? 1 : 0;
+    g.bias = bias; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = Hout * Wout;
+    g.R = R; g.ldr = ldr; g.C = Y; g.ldc = ldy;
+    launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_conv3x3");
+}
+int64_t ldx_op_groupnorm_workspace_floats(int B, int G) { return (int64_t)B * GN_NCHUNK * G * 2; }
+int ldx_op_groupnorm(const void* X, int ldx_, void* Y, int ldy, int B, int HW, int C, int G, float eps, int silu,
+                     const float* gamma, const float* beta, float* workspace, int dtype, void* stream) {
+    if (!X || !Y || !gamma || !beta || !workspace || C % 8 || C % G || G > 32 || ldx_ % 8 || ldy % 8) { set_error("ldx_op_groupnorm: bad argument"); return LDX_EINVAL; }
+    GroupNormArgs a{X, ldx_, Y, ldy, B, HW, C, G, eps, silu, gamma, beta, workspace};
+    launch_groupnorm(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_groupnorm");
+}
+int ldx_op_layernorm(const void* X, int ldx_, void* Y, int ldy, int rows, int C, float eps, const float* gamma, const float* beta, int dtype, void* stream) {
+    if (!X || !Y || !gamma || !beta || C % 8 || C > 2048) { set_error("ldx_op_layernorm: bad argument (C % 8, C <= 2048)"); return LDX_EINVAL; }
+    LayerNormArgs a{X, ldx_, Y, ldy, rows, C, eps, gamma, beta};
+    launch_layernorm(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_layernorm");
+}
+int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
+                     float scale, int causal, int dtype, void* stream) {
+    if (!Q || !K || !V || !O || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160)"); return LDX_EINVAL; }
+    AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal};
+    launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_attention");
+}
+int ldx_op_skinny(const float* x, int ldx_, const void* W, const float* bias, float* out, int ldo, int M, int N, int K, int in_act, int out_act, int dtype, void* stream) {
+    if (!x || !W || !out || K % 8) { set_error("ldx_op_skinny: bad argument"); return LDX_EINVAL; }
+    SkinnyArgs a{x, ldx_, W, bias, out, ldo, M, N, K, in_act, out_act};
+    launch_skinny(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_skinny");
+}
+
+}  // extern "C"

@@ -1,0 +1,762 @@
+// ldx UNet engine: host-side planner / executor behind the C ABI (include/ldx.h).
+//
+// Mirrors, for the accelerated path only, what the reference spreads over
+//   UNetModel1.__init__/forward          src/NeuralNetwork/unet.py:208-770
+//   ResBlock1 / Downsample1 / Upsample1  src/AutoEncoders/ResBlock.py:75-335
+//   SpatialTransformer / BasicTransformerBlock / FeedForward   src/NeuralNetwork/transformer.py:19-377
+//   CrossAttention                       src/Attention/Attention.py:53-124
+//   BaseModel.apply_model                src/Model/ModelBase.py:72-133
+// but as a static launch plan over one activation arena: weights are packed once into MFMA-friendly
+// [N][K] 16-bit matrices (conv3x3 -> [Cout][ky][kx][Cin], q/k/v fused, GEGLU rows slab-interleaved),
+// activations stay NHWC 16-bit, channel concat is a column offset, and every op is one of the HIP
+// kernels in csrc/*.hip.  No CPU fallback exists: without a HIP device every call fails.
+#include "engine.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <thread>
+
+namespace ldx {
+
+thread_local std::string g_last_error;
+void set_error(const std::string& s) { g_last_error = s; }
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return LDX_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------
+// 16-bit conversions on the host (round-to-nearest-even)
+static inline float half_to_float(uint16_t h) {
+    const uint32_t sign = (uint32_t)(h & 0x8000) << 16;
+    uint32_t exp = (h >> 10) & 0x1f, man = h & 0x3ff, out;
+    if (exp == 0) {
+        if (man == 0) out = sign;
+        else {
+            exp = 127 - 15 + 1;
+            while (!(man & 0x400)) { man <<= 1; --exp; }
+            man &= 0x3ff;
+            out = sign | (exp << 23) | (man << 13);
+        }
+    } else if (exp == 31) out = sign | 0x7f800000u | (man << 13);
+    else out = sign | ((exp + 127 - 15) << 23) | (man << 13);
+    float f; memcpy(&f, &out, 4); return f;
+}
+static inline uint16_t float_to_half(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    const uint32_t sign = (x >> 16) & 0x8000;
+    x &= 0x7fffffff;
+    if (x >= 0x7f800000) return (uint16_t)(sign | 0x7c00 | ((x > 0x7f800000) ? 0x200 : 0));
+    if (x >= 0x477ff000) return (uint16_t)(sign | 0x7c00);                       // overflow -> inf
+    if (x < 0x33000001) return (uint16_t)sign;                                  // underflow -> 0
+    int exp = (int)(x >> 23) - 127 + 15;
+    uint32_t man = x & 0x7fffff;
+    if (exp <= 0) {                                                              // subnormal
+        man |= 0x800000;
+        const int shift = 14 - exp;
+        uint32_t hm = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), halfway = 1u << (shift - 1);
+        if (rem > halfway || (rem == halfway && (hm & 1))) ++hm;
+        return (uint16_t)(sign | hm);
+    }
+    uint32_t hm = man >> 13;
+    const uint32_t rem = man & 0x1fff;
+    uint32_t out = ((uint32_t)exp << 10) | hm;
+    if (rem > 0x1000 || (rem == 0x1000 && (hm & 1))) ++out;
+    return (uint16_t)(sign | out);
+}
+static inline float bf16_to_float(uint16_t h) { uint32_t x = (uint32_t)h << 16; float f; memcpy(&f, &x, 4); return f; }
+static inline uint16_t float_to_bf16(float f) {
+    uint32_t x; memcpy(&x, &f, 4);
+    if ((x & 0x7fffffff) > 0x7f800000) return (uint16_t)((x >> 16) | 0x40);
+    x += 0x7fff + ((x >> 16) & 1);
+    return (uint16_t)(x >> 16);
+}
+
+float HostTensor::at(size_t i) const {
+    switch (dtype) {
+        case LDX_F32: return ((const float*)data.data())[i];
+        case LDX_F16: return half_to_float(((const uint16_t*)data.data())[i]);
+        default: return bf16_to_float(((const uint16_t*)data.data())[i]);
+    }
+}
+
+static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn) {
+    unsigned nt = std::thread::hardware_concurrency();
+    if (nt == 0) nt = 4;
+    if (nt > 32) nt = 32;
+    if (n < 1u << 16) { fn(0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (unsigned t = 0; t < nt; ++t) {
+        const size_t b = t * per, e = std::min(n, b + per);
+        if (b >= e) break;
+        th.emplace_back([=, &fn] { fn(b, e); });
+    }
+    for (auto& x : th) x.join();
+}
+
+// ---------------------------------------------------------------------------------------------
+Engine::Engine(const ldx_unet_config& c, int dev) : cfg(c), device(dev) {
+    dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
+}
+Engine::~Engine() {
+    (void)hipSetDevice(device);
+    for (void* p : dev_allocs) (void)hipFree(p);
+    if (arena) (void)hipFree(arena);
+    if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+}
+
+int Engine::validate() const {
+    auto bad = [&](const char* m) { set_error(std::string("unsupported UNet config: ") + m); return LDX_EINVAL; };
+    if (cfg.model_channels <= 0 || cfg.model_channels % 64) return bad("model_channels must be a multiple of 64");
+    if (cfg.context_dim <= 0 || cfg.context_dim % 64) return bad("context_dim must be a multiple of 64");
+    if (cfg.num_levels < 1 || cfg.num_levels > 8) return bad("num_levels out of range");
+    if (cfg.num_heads < 1) return bad("num_heads");
+    if (cfg.in_channels < 1 || cfg.in_channels > 64 || cfg.out_channels < 1 || cfg.out_channels > 128) return bad("in/out channels");
+    for (int l = 0; l < cfg.num_levels; ++l) {
+        const int ch = cfg.model_channels * cfg.channel_mult[l];
+        if (ch % cfg.num_heads || (ch / cfg.num_heads) % 8 || ch / cfg.num_heads > 160) return bad("head dim must be a multiple of 8 and <= 160");
+        if (ch % 32) return bad("channels not divisible by 32 groups");
+    }
+    return LDX_OK;
+}
+
+int Engine::load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
+    if (finalized) { set_error("ldx_load_tensor after ldx_finalize"); return LDX_ESTATE; }
+    if (!key || !data || ndim < 0 || ndim > 8) { set_error("ldx_load_tensor: bad argument"); return LDX_EINVAL; }
+    if (dtype != LDX_F32 && dtype != LDX_F16 && dtype != LDX_BF16) { set_error("ldx_load_tensor: bad dtype"); return LDX_EINVAL; }
+    HostTensor t;
+    t.dtype = dtype;
+    size_t n = 1;
+    for (int i = 0; i < ndim; ++i) { t.shape.push_back(shape[i]); n *= (size_t)shape[i]; }
+    t.numel = n;
+    const size_t esz = dtype == LDX_F32 ? 4 : 2;
+    t.data.resize(n * esz);
+    memcpy(t.data.data(), data, n * esz);
+    host[key] = std::move(t);
+    return LDX_OK;
+}
+
+int Engine::set_tables(const float* ls, int n, const float* temb, int dim) {
+    if (!ls || !temb || n <= 0 || dim != cfg.model_channels) { set_error("ldx_set_tables: bad argument (temb_dim must equal model_channels)"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    void* p = nullptr;
+    HIP_OK(hipMalloc(&p, (size_t)n * 4)); dev_allocs.push_back(p);
+    HIP_OK(hipMemcpy(p, ls, (size_t)n * 4, hipMemcpyHostToDevice));
+    d_log_sigmas = (float*)p; n_sigmas = n;
+    HIP_OK(hipMalloc(&p, (size_t)n * dim * 4)); dev_allocs.push_back(p);
+    HIP_OK(hipMemcpy(p, temb, (size_t)n * dim * 4, hipMemcpyHostToDevice));
+    d_temb = (float*)p;
+    return LDX_OK;
+}
+
+const HostTensor* Engine::get(const std::string& key, std::initializer_list<int64_t> shape) {
+    auto it = host.find(key);
+    if (it == host.end()) { missing = key; return nullptr; }
+    const HostTensor& t = it->second;
+    if (shape.size()) {
+        bool ok = t.shape.size() == shape.size();
+        size_t i = 0;
+        if (ok) for (int64_t s : shape) ok = ok && (t.shape[i++] == s);
+        if (!ok) { missing = key + " (shape mismatch)"; return nullptr; }
+    }
+    return &t;
+}
+
+// upload a [rows][cols] matrix produced by getter(r, c) as 16-bit
+void* Engine::upload16(size_t rows, size_t cols, const std::function<float(size_t, size_t)>& getter) {
+    std::vector<uint16_t> buf(rows * cols);
+    const bool bf = dt == DT_BF16;
+    parallel_for(rows, [&](size_t b, size_t e) {
+        for (size_t r = b; r < e; ++r)
+            for (size_t c = 0; c < cols; ++c) {
+                const float v = getter(r, c);
+                buf[r * cols + c] = bf ? float_to_bf16(v) : float_to_half(v);
+            }
+    });
+    void* p = nullptr;
+    if (hipMalloc(&p, buf.size() * 2) != hipSuccess) return nullptr;
+    dev_allocs.push_back(p);
+    if (hipMemcpy(p, buf.data(), buf.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    weight_bytes += buf.size() * 2;
+    return p;
+}
+float* Engine::upload32(size_t n, const std::function<float(size_t)>& getter) {
+    std::vector<float> buf(n);
+    for (size_t i = 0; i < n; ++i) buf[i] = getter(i);
+    void* p = nullptr;
+    if (hipMalloc(&p, n * 4) != hipSuccess) return nullptr;
+    dev_allocs.push_back(p);
+    if (hipMemcpy(p, buf.data(), n * 4, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+    weight_bytes += n * 4;
+    return (float*)p;
+}
+
+bool Engine::mk_linear(const std::string& pre, int N, int K, bool bias, LinearW& out, bool conv1x1) {
+    const HostTensor* w = conv1x1 ? get(pre + ".weight", {N, K, 1, 1}) : get(pre + ".weight", {N, K});
+    if (!w) return false;
+    out.N = N; out.K = K;
+    out.w = upload16(N, K, [&](size_t r, size_t c) { return w->at(r * K + c); });
+    out.b = nullptr;
+    if (bias) {
+        const HostTensor* b = get(pre + ".bias", {N});
+        if (!b) return false;
+        out.b = upload32(N, [&](size_t i) { return b->at(i); });
+        if (!out.b) return false;
+    }
+    return out.w != nullptr;
+}
+bool Engine::mk_conv3(const std::string& pre, int Cout, int Cin, int CinPad, LinearW& out) {
+    const HostTensor* w = get(pre + ".weight", {Cout, Cin, 3, 3});
+    const HostTensor* b = get(pre + ".bias", {Cout});
+    if (!w || !b) return false;
+    out.N = Cout; out.K = 9 * CinPad;
+    // [Cout][ky][kx][CinPad]  <-  [Cout][Cin][ky][kx]
+    out.w = upload16(Cout, (size_t)9 * CinPad, [&](size_t r, size_t c) {
+        const size_t tap = c / CinPad, ci = c % CinPad;
+        if ((int)ci >= Cin) return 0.f;
+        return w->at((r * Cin + ci) * 9 + tap);
+    });
+    out.b = upload32(Cout, [&](size_t i) { return b->at(i); });
+    return out.w && out.b;
+}
+bool Engine::mk_norm(const std::string& pre, int C, NormW& out) {
+    const HostTensor* w = get(pre + ".weight", {C});
+    const HostTensor* b = get(pre + ".bias", {C});
+    if (!w || !b) return false;
+    out.C = C;
+    out.g = upload32(C, [&](size_t i) { return w->at(i); });
+    out.b = upload32(C, [&](size_t i) { return b->at(i); });
+    return out.g && out.b;
+}
+
+bool Engine::mk_res(const std::string& pre, int Cin, int Cout, ResW& r) {
+    r.Cin = Cin; r.Cout = Cout;
+    if (!mk_norm(pre + ".in_layers.0", Cin, r.gn1)) return false;
+    if (!mk_conv3(pre + ".in_layers.2", Cout, Cin, Cin, r.conv1)) return false;
+    // emb_layers.1 is batched with every other ResBlock's projection (one skinny GEMM per forward)
+    const HostTensor* ew = get(pre + ".emb_layers.1.weight", {Cout, 4 * cfg.model_channels});
+    const HostTensor* eb = get(pre + ".emb_layers.1.bias", {Cout});
+    if (!ew || !eb) return false;
+    r.emb_off = emb_total;
+    emb_total += Cout;
+    emb_srcs.push_back({ew, eb, Cout});
+    if (!mk_norm(pre + ".out_layers.0", Cout, r.gn2)) return false;
+    if (!mk_conv3(pre + ".out_layers.3", Cout, Cout, Cout, r.conv2)) return false;
+    r.has_skip = Cin != Cout;
+    if (r.has_skip && !mk_linear(pre + ".skip_connection", Cout, Cin, true, r.skip, true)) return false;
+    return true;
+}
+
+bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
+    x.C = C; x.depth = depth;
+    const int ctx = cfg.context_dim;
+    if (!mk_norm(pre + ".norm", C, x.gn)) return false;
+    if (!mk_linear(pre + ".proj_in", C, C, true, x.proj_in, true)) return false;
+    if (!mk_linear(pre + ".proj_out", C, C, true, x.proj_out, true)) return false;
+    x.blocks.resize(depth);
+    for (int d = 0; d < depth; ++d) {
+        XfBlockW& b = x.blocks[d];
+        const std::string bp = pre + ".transformer_blocks." + std::to_string(d);
+        if (!mk_norm(bp + ".norm1", C, b.ln1) || !mk_norm(bp + ".norm2", C, b.ln2) || !mk_norm(bp + ".norm3", C, b.ln3)) return false;
+        // fused q|k|v for self attention
+        const HostTensor* q = get(bp + ".attn1.to_q.weight", {C, C});
+        const HostTensor* k = get(bp + ".attn1.to_k.weight", {C, C});
+        const HostTensor* v = get(bp + ".attn1.to_v.weight", {C, C});
+        if (!q || !k || !v) return false;
+        b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.b = nullptr;
+        b.qkv.w = upload16((size_t)3 * C, C, [&](size_t r, size_t c) {
+            const HostTensor* s = r < (size_t)C ? q : (r < (size_t)2 * C ? k : v);
+            return s->at((r % C) * C + c);
+        });
+        if (!b.qkv.w) return false;
+        if (!mk_linear(bp + ".attn1.to_out.0", C, C, true, b.o1)) return false;
+        if (!mk_linear(bp + ".attn2.to_q", C, C, false, b.q2)) return false;
+        const HostTensor* k2 = get(bp + ".attn2.to_k.weight", {C, ctx});
+        const HostTensor* v2 = get(bp + ".attn2.to_v.weight", {C, ctx});
+        if (!k2 || !v2) return false;
+        b.kv2.N = 2 * C; b.kv2.K = ctx; b.kv2.b = nullptr;
+        b.kv2.w = upload16((size_t)2 * C, ctx, [&](size_t r, size_t c) {
+            const HostTensor* s = r < (size_t)C ? k2 : v2;
+            return s->at((r % C) * ctx + c);
+        });
+        if (!b.kv2.w) return false;
+        if (!mk_linear(bp + ".attn2.to_out.0", C, C, true, b.o2)) return false;
+        // GEGLU projection: rows permuted so each 64-column slab holds 32 value rows then their 32 gate rows
+        const int inner = 4 * C;
+        const HostTensor* fw = get(bp + ".ff.net.0.proj.weight", {2 * inner, C});
+        const HostTensor* fb = get(bp + ".ff.net.0.proj.bias", {2 * inner});
+        if (!fw || !fb) return false;
+        auto src_row = [inner](size_t r) { const size_t slab = r / 64, within = r % 64; return within < 32 ? slab * 32 + within : inner + slab * 32 + (within - 32); };
+        b.ff1.N = 2 * inner; b.ff1.K = C;
+        b.ff1.w = upload16((size_t)2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); });
+        b.ff1.b = upload32((size_t)2 * inner, [&](size_t i) { return fb->at(src_row(i)); });
+        if (!b.ff1.w || !b.ff1.b) return false;
+        if (!mk_linear(bp + ".ff.net.2", C, inner, true, b.ff2)) return false;
+    }
+    return true;
+}
+
+int Engine::finalize() {
+    if (finalized) return LDX_OK;
+    int rc = validate();
+    if (rc) return rc;
+    HIP_OK(hipSetDevice(device));
+    if (!d_log_sigmas) { set_error("ldx_finalize: call ldx_set_tables first"); return LDX_ESTATE; }
+    const int mc = cfg.model_channels, ted = 4 * mc;
+    bool ok = true;
+    // --- structure walk, identical in order to UNetModel1.__init__ (unet.py:344-677) ---
+    ok = ok && mk_linear("time_embed.0", ted, mc, true, te0) && mk_linear("time_embed.2", ted, ted, true, te2);
+    ok = ok && mk_conv3("input_blocks.0.0", mc, cfg.in_channels, 64, conv_in);
+    int ch = mc, td_i = 0, ib = 1;
+    std::vector<int> chans{mc};
+    for (int level = 0; ok && level < cfg.num_levels; ++level) {
+        for (int nr = 0; ok && nr < cfg.num_res_blocks[level]; ++nr) {
+            BlockW blk;
+            const std::string pre = "input_blocks." + std::to_string(ib);
+            const int co = cfg.channel_mult[level] * mc;
+            blk.has_res = true;
+            ok = ok && mk_res(pre + ".0", ch, co, blk.res);
+            ch = co;
+            const int depth = cfg.transformer_depth[td_i++];
+            if (ok && depth > 0) { blk.has_xf = true; ok = mk_xf(pre + ".1", ch, depth, blk.xf); }
+            in_blocks.push_back(std::move(blk)); chans.push_back(ch); ++ib;
+        }
+        if (ok && level != cfg.num_levels - 1) {
+            BlockW blk; blk.has_down = true;
+            ok = mk_conv3("input_blocks." + std::to_string(ib) + ".0.op", ch, ch, ch, blk.down);
+            in_blocks.push_back(std::move(blk)); chans.push_back(ch); ++ib;
+        }
+    }
+    if (ok && cfg.transformer_depth_middle >= -1) {
+        has_middle = true;
+        ok = mk_res("middle_block.0", ch, ch, mid_res0);
+        if (ok && cfg.transformer_depth_middle >= 0) {
+            mid_has_xf = true;
+            ok = mk_xf("middle_block.1", ch, std::max(1, (int)cfg.transformer_depth_middle), mid_xf) && mk_res("middle_block.2", ch, ch, mid_res1);
+            if (cfg.transformer_depth_middle == 0) { set_error("transformer_depth_middle == 0 unsupported"); return LDX_EINVAL; }
+        }
+    }
+    int n_out = 0;
+    for (int l = 0; l < cfg.num_levels; ++l) n_out += cfg.num_res_blocks[l] + 1;
+    int td_o = n_out, ob = 0;
+    for (int level = cfg.num_levels - 1; ok && level >= 0; --level) {
+        for (int i = 0; ok && i <= cfg.num_res_blocks[level]; ++i) {
+            BlockW blk;
+            const std::string pre = "output_blocks." + std::to_string(ob);
+            const int ich = chans.back(); chans.pop_back();
+            const int co = mc * cfg.channel_mult[level];
+            blk.has_res = true; blk.skip_ch = ich;
+            ok = mk_res(pre + ".0", ch + ich, co, blk.res);
+            ch = co;
+            int sub = 1;
+            const int depth = cfg.transformer_depth_output[--td_o];
+            if (ok && depth > 0) { blk.has_xf = true; ok = mk_xf(pre + ".1", ch, depth, blk.xf); ++sub; }
+            if (ok && level && i == cfg.num_res_blocks[level]) {
+                blk.has_up = true;
+                ok = mk_conv3(pre + "." + std::to_string(sub) + ".conv", ch, ch, ch, blk.up);
+            }
+            out_blocks.push_back(std::move(blk)); ++ob;
+        }
+    }
+    ok = ok && mk_norm("out.0", ch, out_gn) && mk_conv3("out.2", cfg.out_channels, mc, mc, conv_out);
+    if (ok) {
+        // batched emb_layers: [emb_total][4*mc]
+        std::vector<size_t> starts; size_t acc = 0;
+        for (auto& s : emb_srcs) { starts.push_back(acc); acc += s.n; }
+        auto find = [&](size_t r) { size_t i = std::upper_bound(starts.begin(), starts.end(), r) - starts.begin() - 1; return i; };
+        emb_all.N = emb_total; emb_all.K = ted;
+        emb_all.w = upload16(emb_total, ted, [&](size_t r, size_t c) { const size_t i = find(r); return emb_srcs[i].w->at((r - starts[i]) * ted + c); });
+        emb_all.b = upload32(emb_total, [&](size_t r) { const size_t i = find(r); return emb_srcs[i].b->at(r - starts[i]); });
+        ok = emb_all.w && emb_all.b;
+    }
+    if (!ok) {
+        if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
+        set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
+        return LDX_EHIP;
+    }
+    emb_srcs.clear();
+    host.clear();
+    finalized = true;
+    return LDX_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// arena allocator used at plan time (offsets), first-fit with coalescing
+size_t Engine::a_alloc(size_t bytes) {
+    bytes = (bytes + 255) & ~(size_t)255;
+    for (size_t i = 0; i < free_list.size(); ++i) {
+        if (free_list[i].second >= bytes) {
+            const size_t off = free_list[i].first;
+            if (free_list[i].second == bytes) free_list.erase(free_list.begin() + i);
+            else { free_list[i].first += bytes; free_list[i].second -= bytes; }
+            live[off] = bytes;
+            return off;
+        }
+    }
+    const size_t off = arena_top;
+    arena_top += bytes;
+    arena_peak = std::max(arena_peak, arena_top);
+    live[off] = bytes;
+    return off;
+}
+void Engine::a_free(size_t off) {
+    auto it = live.find(off);
+    if (it == live.end()) return;
+    size_t sz = it->second;
+    live.erase(it);
+    free_list.emplace_back(off, sz);
+    std::sort(free_list.begin(), free_list.end());
+    for (size_t i = 0; i + 1 < free_list.size();) {
+        if (free_list[i].first + free_list[i].second == free_list[i + 1].first) {
+            free_list[i].second += free_list[i + 1].second;
+            free_list.erase(free_list.begin() + i + 1);
+        } else ++i;
+    }
+    if (!free_list.empty() && free_list.back().first + free_list.back().second == arena_top) {
+        arena_top = free_list.back().first;
+        free_list.pop_back();
+    }
+}
+
+// ---- op emitters ---------------------------------------------------------------------------------
+void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bool geglu, const float* rowvec, int rv_ld, int rpb) {
+    Op o{}; o.kind = OP_GEMM; o.name = name;
+    GemmArgs& g = o.g;
+    g.A = ptr(A); g.lda = A.ld; g.W = w.w; g.M = A.rows; g.N = w.N; g.K = w.K; g.mode = 0;
+    g.bias = w.b; g.rowvec = rowvec; g.rowvec_ld = rv_ld; g.rows_per_batch = rpb > 0 ? rpb : 1;
+    g.geglu = geglu ? 1 : 0;
+    g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
+    g.C = ptr(C); g.ldc = C.ld; g.Cf = nullptr;
+    ops.push_back(o);
+    flops += 2.0 * g.M * (double)g.N * g.K;
+}
+void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, const LinearW& w, int stride, int Hout, int Wout,
+                     Act Y, Act R, const float* rowvec, int rv_ld, float* Cf, int ldcf) {
+    Op o{}; o.kind = OP_GEMM; o.name = name;
+    GemmArgs& g = o.g;
+    g.A = ptr(X); g.lda = X.ld; g.W = w.w; g.M = B * Hout * Wout; g.N = w.N; g.K = w.K; g.mode = 1;
+    g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Hout = Hout; g.Wout = Wout; g.stride = stride;
+    if (stride == 1) { g.Hv = Hout; g.Wv = Wout; } else { g.Hv = Hin; g.Wv = Win; }
+    g.resize = (g.Hv != Hin || g.Wv != Win) ? 1 : 0;
+    g.bias = w.b; g.rowvec = rowvec; g.rowvec_ld = rv_ld; g.rows_per_batch = Hout * Wout;
+    g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
+    g.C = Y.valid ? ptr(Y) : nullptr; g.ldc = Y.ld; g.Cf = Cf; g.ldcf = ldcf;
+    ops.push_back(o);
+    flops += 2.0 * g.M * (double)g.N * g.K;
+}
+void Engine::op_gn(const char* name, Act X, Act Y, int B, int HW, const NormW& n, float eps, bool silu) {
+    Op o{}; o.kind = OP_GN; o.name = name;
+    GroupNormArgs& g = o.gn;
+    g.X = ptr(X); g.ldx = X.ld; g.Y = ptr(Y); g.ldy = Y.ld; g.B = B; g.HW = HW; g.C = n.C; g.G = 32; g.eps = eps; g.silu = silu;
+    g.gamma = n.g; g.beta = n.b; g.partial = (float*)(arena ? (char*)arena + gn_ws_off : nullptr);
+    ops.push_back(o);
+}
+void Engine::op_ln(const char* name, Act X, Act Y, const NormW& n) {
+    Op o{}; o.kind = OP_LN; o.name = name;
+    LayerNormArgs& l = o.ln;
+    l.X = ptr(X); l.ldx = X.ld; l.Y = ptr(Y); l.ldy = Y.ld; l.rows = X.rows; l.C = n.C; l.eps = 1e-5f; l.gamma = n.g; l.beta = n.b;
+    ops.push_back(o);
+}
+void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, Act O, int B, int H, int Nq, int Mk, int D) {
+    Op o{}; o.kind = OP_ATTN; o.name = name;
+    AttnArgs& a = o.at;
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ptr(O); a.ldo = O.ld;
+    a.B = B; a.H = H; a.Nq = Nq; a.Mk = Mk; a.D = D; a.scale = 1.0f / std::sqrt((float)D); a.causal = 0;
+    ops.push_back(o);
+    flops += 4.0 * B * H * (double)Nq * Mk * D;
+}
+
+Act Engine::new_act(int rows, int C) {
+    Act a; a.valid = true; a.owned = true; a.rows = rows; a.C = C; a.ld = C; a.col = 0;
+    a.off = a_alloc((size_t)rows * C * 2);
+    return a;
+}
+Act Engine::view(const Act& base, int col, int C) {
+    Act a = base; a.owned = false; a.col = base.col + col; a.C = C; return a;
+}
+void Engine::release(const Act& a) { if (a.valid && a.owned) a_free(a.off); }
+
+// ResBlock1._forward (ResBlock.py:315-335)
+void Engine::emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W) {
+    const int M = B * H * W;
+    Act t1 = new_act(M, r.Cin);
+    op_gn("res.gn1", X, t1, B, H * W, r.gn1, 1e-5f, true);
+    Act t2 = new_act(M, r.Cout);
+    op_conv("res.conv1", t1, B, H, W, r.Cin, r.conv1, 1, H, W, t2, Act{}, d_emb_all ? d_emb_all + r.emb_off : nullptr, emb_total);
+    release(t1);
+    Act t3 = new_act(M, r.Cout);
+    op_gn("res.gn2", t2, t3, B, H * W, r.gn2, 1e-5f, true);
+    release(t2);
+    if (r.has_skip) {
+        Act t4 = new_act(M, r.Cout);
+        op_gemm("res.skip", X, r.skip, t4, Act{});
+        op_conv("res.conv2", t3, B, H, W, r.Cout, r.conv2, 1, H, W, OUT, t4);
+        release(t4);
+    } else {
+        op_conv("res.conv2", t3, B, H, W, r.Cout, r.conv2, 1, H, W, OUT, X);
+    }
+    release(t3);
+}
+
+// SpatialTransformer.forward (transformer.py:342-377) + BasicTransformerBlock._forward (:186-245)
+void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc) {
+    const int M = B * H * W, C = x.C, heads = cfg.num_heads, D = C / heads;
+    Act t1 = new_act(M, C);
+    op_gn("xf.norm", X, t1, B, H * W, x.gn, 1e-6f, false);
+    Act h = new_act(M, C);
+    op_gemm("xf.proj_in", t1, x.proj_in, h, Act{});
+    release(t1);
+    for (int d = 0; d < x.depth; ++d) {
+        const XfBlockW& b = x.blocks[d];
+        Act n = new_act(M, C);
+        op_ln("xf.ln1", h, n, b.ln1);
+        Act qkv = new_act(M, 3 * C);
+        op_gemm("xf.qkv", n, b.qkv, qkv, Act{});
+        Act a = new_act(M, C);
+        const char* base = (const char*)ptr(qkv);
+        op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
+        release(qkv);
+        op_gemm("xf.o1", a, b.o1, h, h);                       // x += attn1(norm1(x))   (in place)
+        op_ln("xf.ln2", h, n, b.ln2);
+        Act q = new_act(M, C);
+        op_gemm("xf.q2", n, b.q2, q, Act{});
+        Act kv = new_act(B * Mc, 2 * C);
+        op_gemm("xf.kv2", ctx16, b.kv2, kv, Act{});
+        const char* kvb = (const char*)ptr(kv);
+        op_attn("xf.attn2", ptr(q), C, kvb, 2 * C, kvb + (size_t)C * 2, 2 * C, a, B, heads, H * W, Mc, D);
+        release(q); release(kv);
+        op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
+        release(a);
+        op_ln("xf.ln3", h, n, b.ln3);
+        Act f = new_act(M, 4 * C);
+        op_gemm("xf.ff1", n, b.ff1, f, Act{}, true);           // GEGLU
+        release(n);
+        op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
+        release(f);
+    }
+    op_gemm("xf.proj_out", h, x.proj_out, OUT, X);             // + x_in
+    release(h);
+}
+
+int Engine::plan(int B2, int h, int w, int Mc) {
+    // dry run (arena == nullptr) measures the peak; second run binds real pointers
+    for (int pass = 0; pass < 2; ++pass) {
+        ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
+        if (pass == 1) {
+            if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
+            if (!arena) { HIP_OK(hipMalloc(&arena, arena_peak_dry)); arena_cap = arena_peak_dry; }
+        }
+        const bool bind = pass == 1;
+        void* saved_arena = arena;
+        if (!bind) arena = nullptr;
+        const int mc = cfg.model_channels, ted = 4 * mc;
+        // fixed small buffers
+        const size_t o_temb = a_alloc((size_t)B2 * mc * 4), o_e1 = a_alloc((size_t)B2 * ted * 4), o_e2 = a_alloc((size_t)B2 * ted * 4);
+        const size_t o_emb = a_alloc((size_t)B2 * emb_total * 4);
+        gn_ws_off = a_alloc((size_t)B2 * GN_NCHUNK * 32 * 2 * 4);
+        const size_t o_eps = a_alloc((size_t)B2 * h * w * cfg.out_channels * 4);
+        auto f32p = [&](size_t off) { return bind ? (float*)((char*)arena + off) : (float*)nullptr; };
+        d_temb_out = f32p(o_temb); d_e1 = f32p(o_e1); d_e2 = f32p(o_e2); d_emb_all = f32p(o_emb); d_eps = f32p(o_eps);
+
+        // ---- level geometry & concat buffers (so skips are written in place, no torch.cat copy) ----
+        struct Skip { Act act; int H, W; };
+        std::vector<int> Hs{h}, Ws{w};
+        for (int l = 1; l < cfg.num_levels; ++l) { Hs.push_back((Hs.back() + 1) / 2); Ws.push_back((Ws.back() + 1) / 2); }
+        // simulate the channel bookkeeping of the ctor to size the concat buffers of the output blocks
+        std::vector<int> in_ch{mc}, in_lv{0};
+        { int c = mc; for (int l = 0; l < cfg.num_levels; ++l) { for (int r = 0; r < cfg.num_res_blocks[l]; ++r) { c = mc * cfg.channel_mult[l]; in_ch.push_back(c); in_lv.push_back(l); }
+              if (l != cfg.num_levels - 1) { in_ch.push_back(c); in_lv.push_back(l + 1); } } }
+        const int n_skips = (int)in_ch.size();
+        // output block k consumes skip (n_skips-1-k); its h channels:
+        std::vector<int> out_hch(n_skips);
+        { int c = in_ch.back(); int k = 0;
+          for (int l = cfg.num_levels - 1; l >= 0; --l) for (int i = 0; i <= cfg.num_res_blocks[l]; ++i) { out_hch[k++] = c; c = mc * cfg.channel_mult[l]; } }
+        std::vector<Act> cat(n_skips);
+        for (int k = 0; k < n_skips; ++k) {
+            const int s = n_skips - 1 - k, lv = in_lv[s];
+            cat[k] = new_act(B2 * Hs[lv] * Ws[lv], out_hch[k] + in_ch[s]);
+        }
+        auto skip_view = [&](int s) { const int k = n_skips - 1 - s; return view(cat[k], out_hch[k], in_ch[s]); };
+
+        // ---- ops ----
+        Op po{}; po.kind = OP_PREP; po.name = "prep"; ops.push_back(po);          // pointers filled per call
+        Act xin = new_act(B2 * h * w, 64);
+        prep_xc_off = xin.off;
+        Act ctx16 = new_act(B2 * Mc, cfg.context_dim);
+        { Op o{}; o.kind = OP_CVT; o.name = "ctx.cvt"; o.cvt_out = ptr(ctx16); o.cvt_n = (size_t)B2 * Mc * cfg.context_dim; ops.push_back(o); }
+        { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.0"; o.sk = SkinnyArgs{d_temb_out, mc, te0.w, te0.b, d_e1, ted, B2, ted, mc, 0, 1}; ops.push_back(o); }
+        { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.2"; o.sk = SkinnyArgs{d_e1, ted, te2.w, te2.b, d_e2, ted, B2, ted, ted, 0, 1}; ops.push_back(o); }
+        { Op o{}; o.kind = OP_SKINNY; o.name = "emb_layers"; o.sk = SkinnyArgs{d_e2, ted, emb_all.w, emb_all.b, d_emb_all, emb_total, B2, emb_total, ted, 0, 0}; ops.push_back(o); }
+        flops += 2.0 * B2 * ((double)ted * mc + (double)ted * ted + (double)emb_total * ted);
+
+        int lv = 0, s = 0;
+        Act hcur = skip_view(0);
+        op_conv("conv_in", xin, B2, h, w, 64, conv_in, 1, h, w, hcur, Act{});
+        flops -= 2.0 * B2 * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);   // padded channels are not algorithmic work
+        release(xin);
+        for (auto& blk : in_blocks) {
+            ++s;
+            Act dst = skip_view(s);
+            if (blk.has_down) {
+                op_conv("down", hcur, B2, Hs[lv], Ws[lv], in_ch[s - 1], blk.down, 2, Hs[lv + 1], Ws[lv + 1], dst, Act{});
+                ++lv;
+            } else if (blk.has_xf) {
+                Act mid = new_act(B2 * Hs[lv] * Ws[lv], blk.res.Cout);
+                emit_res(blk.res, hcur, mid, B2, Hs[lv], Ws[lv]);
+                emit_xf(blk.xf, mid, dst, B2, Hs[lv], Ws[lv], ctx16, Mc);
+                release(mid);
+            } else {
+                emit_res(blk.res, hcur, dst, B2, Hs[lv], Ws[lv]);
+            }
+            hcur = dst;
+        }
+        // middle block (unet.py:537-584); its last op writes column 0 of the first concat buffer
+        {
+            const int Mm = B2 * Hs[lv] * Ws[lv];
+            Act dst = view(cat[0], 0, out_hch[0]);
+            if (!has_middle) { set_error("UNet config without a middle block is not supported by the planner"); arena = saved_arena; return LDX_EINVAL; }
+            if (mid_has_xf) {
+                Act m0 = new_act(Mm, mid_res0.Cout);
+                emit_res(mid_res0, hcur, m0, B2, Hs[lv], Ws[lv]);
+                Act m1 = new_act(Mm, mid_res0.Cout);
+                emit_xf(mid_xf, m0, m1, B2, Hs[lv], Ws[lv], ctx16, Mc);
+                release(m0);
+                emit_res(mid_res1, m1, dst, B2, Hs[lv], Ws[lv]);
+                release(m1);
+            } else {
+                emit_res(mid_res0, hcur, dst, B2, Hs[lv], Ws[lv]);
+            }
+        }
+        // output blocks: input of block k is the whole concat buffer cat[k]
+        int k = 0;
+        Act final_h{};
+        for (auto& blk : out_blocks) {
+            const int sidx = n_skips - 1 - k; (void)sidx;
+            const bool last = (k == n_skips - 1);
+            const int Hc = Hs[lv], Wc = Ws[lv], Mrows = B2 * Hc * Wc;
+            // where does this block's result go?  column 0 of the next concat buffer (at the next block's resolution)
+            const int co = blk.res.Cout;
+            int nsub = 1 + (blk.has_xf ? 1 : 0) + (blk.has_up ? 1 : 0);
+            auto target = [&](bool is_final_sub, int rows) -> Act {
+                if (is_final_sub && !last) return view(cat[k + 1], 0, out_hch[k + 1]);
+                return new_act(rows, co);
+            };
+            int sub = 0;
+            Act cur = cat[k];
+            Act r_out = target(++sub == nsub, Mrows);
+            emit_res(blk.res, cur, r_out, B2, Hc, Wc);
+            release(cat[k]);
+            cur = r_out;
+            if (blk.has_xf) {
+                Act x_out = target(++sub == nsub, Mrows);
+                emit_xf(blk.xf, cur, x_out, B2, Hc, Wc, ctx16, Mc);
+                release(cur);
+                cur = x_out;
+            }
+            if (blk.has_up) {
+                const int Hn = Hs[lv - 1], Wn = Ws[lv - 1];       // output_shape = hs[-1].shape (unet.py:754)
+                Act u_out = target(++sub == nsub, B2 * Hn * Wn);
+                op_conv("up", cur, B2, Hc, Wc, co, blk.up, 1, Hn, Wn, u_out, Act{});
+                release(cur);
+                cur = u_out; --lv;
+            }
+            final_h = cur;
+            ++k;
+        }
+        // out: GroupNorm -> SiLU -> conv3x3 (unet.py:663-677), fp32 NHWC eps
+        {
+            const int Mrows = B2 * h * w;
+            Act t = new_act(Mrows, mc);
+            op_gn("out.gn", final_h, t, B2, h * w, out_gn, 1e-5f, true);
+            release(final_h);
+            op_conv("out.conv", t, B2, h, w, mc, conv_out, 1, h, w, Act{}, Act{}, nullptr, 0, d_eps, cfg.out_channels);
+            release(t);
+        }
+        { Op o{}; o.kind = OP_FINISH; o.name = "finish"; ops.push_back(o); }
+        release(ctx16);
+        if (!bind) { arena_peak_dry = arena_peak; arena = saved_arena; }
+    }
+    pB2 = B2; ph = h; pw = w; pM = Mc;
+    graph_valid = false; warm = false;
+    return LDX_OK;
+}
+
+int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st) {
+    if (!finalized) { set_error("ldx_unet_*: engine not finalized"); return LDX_ESTATE; }
+    if (!x || !sigma_or_t || !ctx || !out || B2 <= 0 || h <= 0 || w <= 0 || Mc <= 0) { set_error("ldx_unet_*: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    if (B2 != pB2 || h != ph || w != pw || Mc != pM) {
+        HIP_OK(hipStreamSynchronize(st));
+        int rc = plan(B2, h, w, Mc);
+        if (rc) return rc;
+    }
+    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise);
+    if (graph_mode && graph_valid && same) {
+        HIP_OK(hipGraphLaunch(graph_exec, st));
+        return LDX_OK;
+    }
+    // capture only once the same (plan, pointers) have been run eagerly before: the first eager pass
+    // also performs the one-time hipFuncSetAttribute calls, which are illegal during capture.
+    const bool use_graph = graph_mode && warm && same;
+    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; warm = true;
+    hipStream_t ls = st;
+    if (use_graph) {
+        if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
+        if (!cap_stream) HIP_OK(hipStreamCreateWithFlags(&cap_stream, hipStreamNonBlocking));
+        HIP_OK(hipStreamSynchronize(st));
+        HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
+        ls = cap_stream;
+    }
+    for (const Op& o : ops) {
+        switch (o.kind) {
+            case OP_PREP: {
+                PrepArgs p{};
+                p.x = x; p.sigma = sigma_or_t; p.B = B2; p.C = cfg.in_channels; p.H = h; p.W = w; p.Cpad = 64;
+                p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
+                p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
+                p.scale_input = denoise ? 1 : 0; p.t_in = denoise ? nullptr : sigma_or_t;
+                launch_prep(p, dt, ls);
+            } break;
+            case OP_CVT: launch_f32_to_t(ctx, o.cvt_out, o.cvt_n, dt, ls); break;
+            case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
+            case OP_GEMM: launch_gemm(o.g, dt, ls); break;
+            case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
+            case OP_LN: launch_layernorm(o.ln, dt, ls); break;
+            case OP_ATTN: launch_attention(o.at, dt, ls); break;
+            case OP_FINISH: {
+                FinishArgs f{};
+                f.eps = d_eps; f.ld = cfg.out_channels; f.x = denoise ? x : nullptr; f.sigma = sigma_or_t; f.out = out;
+                f.B = B2; f.C = cfg.out_channels; f.HW = h * w;
+                launch_finish(f, ls);
+            } break;
+        }
+    }
+    if (use_graph) {
+        hipGraph_t g = nullptr;
+        HIP_OK(hipStreamEndCapture(cap_stream, &g));
+        HIP_OK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
+        (void)hipGraphDestroy(g);
+        graph_valid = true;
+        HIP_OK(hipGraphLaunch(graph_exec, st));
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+int64_t Engine::n_launches() const {
+    int64_t n = 0;
+    for (const Op& o : ops) n += (o.kind == OP_GN || o.kind == OP_PREP) ? 2 : 1;
+    return n;
+}
+
+}  // namespace ldx

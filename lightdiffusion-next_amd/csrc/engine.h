@@ -1,0 +1,122 @@
+// Internal declarations of the ldx UNet engine (see engine.cpp).
+#pragma once
+#include <functional>
+#include <initializer_list>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <utility>
+#include <vector>
+
+#include "../../include/ldx.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+extern thread_local std::string g_last_error;
+void set_error(const std::string& s);
+
+struct HostTensor {
+    int dtype = LDX_F32;
+    std::vector<int64_t> shape;
+    std::vector<uint8_t> data;
+    size_t numel = 0;
+    float at(size_t i) const;
+};
+
+struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
+struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0; };
+struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; };
+struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };
+struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up = false; ResW res; XfW xf; LinearW down, up; int skip_ch = 0; };
+
+// activation view inside the arena: rows x C 16-bit elements, row stride ld, starting at column col
+struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 0, C = 0, ld = 0, col = 0; };
+
+enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH };
+struct Op {
+    OpKind kind; const char* name;
+    GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk;
+    void* cvt_out; size_t cvt_n;
+};
+
+struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
+
+class Engine {
+public:
+    Engine(const ldx_unet_config& c, int dev);
+    ~Engine();
+    int validate() const;
+    int load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
+    int set_tables(const float* ls, int n, const float* temb, int dim);
+    int finalize();
+    int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st);
+    int plan(int B2, int h, int w, int Mc);
+    int64_t n_launches() const;
+
+    ldx_unet_config cfg;
+    int device;
+    DType dt;
+    bool finalized = false;
+    bool graph_mode = false;
+    double flops = 0;
+    size_t arena_cap = 0, arena_peak_dry = 0;
+    size_t weight_bytes = 0;
+    int pB2 = 0, ph = 0, pw = 0, pM = 0;
+
+private:
+    // weights
+    std::unordered_map<std::string, HostTensor> host;
+    std::string missing;
+    std::vector<void*> dev_allocs;
+    const HostTensor* get(const std::string& key, std::initializer_list<int64_t> shape);
+    void* upload16(size_t rows, size_t cols, const std::function<float(size_t, size_t)>& getter);
+    float* upload32(size_t n, const std::function<float(size_t)>& getter);
+    bool mk_linear(const std::string& pre, int N, int K, bool bias, LinearW& out, bool conv1x1 = false);
+    bool mk_conv3(const std::string& pre, int Cout, int Cin, int CinPad, LinearW& out);
+    bool mk_norm(const std::string& pre, int C, NormW& out);
+    bool mk_res(const std::string& pre, int Cin, int Cout, ResW& r);
+    bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
+
+    LinearW te0, te2, conv_in, conv_out, emb_all;
+    NormW out_gn;
+    std::vector<BlockW> in_blocks, out_blocks;
+    bool has_middle = false, mid_has_xf = false;
+    ResW mid_res0, mid_res1;
+    XfW mid_xf;
+    int emb_total = 0;
+    std::vector<EmbSrc> emb_srcs;
+    float* d_log_sigmas = nullptr; float* d_temb = nullptr; int n_sigmas = 0;
+
+    // plan
+    void* arena = nullptr;
+    std::vector<Op> ops;
+    std::vector<std::pair<size_t, size_t>> free_list;
+    std::map<size_t, size_t> live;
+    size_t arena_top = 0, arena_peak = 0;
+    size_t gn_ws_off = 0, prep_xc_off = 0;
+    float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
+    size_t a_alloc(size_t bytes);
+    void a_free(size_t off);
+    void* ptr(const Act& a) const { return (void*)((uintptr_t)arena + a.off + (size_t)a.col * 2); }
+    Act new_act(int rows, int C);
+    Act view(const Act& base, int col, int C);
+    void release(const Act& a);
+    void op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bool geglu = false, const float* rowvec = nullptr, int rv_ld = 0, int rpb = 0);
+    void op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, const LinearW& w, int stride, int Hout, int Wout,
+                 Act Y, Act R, const float* rowvec = nullptr, int rv_ld = 0, float* Cf = nullptr, int ldcf = 0);
+    void op_gn(const char* name, Act X, Act Y, int B, int HW, const NormW& n, float eps, bool silu);
+    void op_ln(const char* name, Act X, Act Y, const NormW& n);
+    void op_attn(const char* name, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, Act O, int B, int H, int Nq, int Mk, int D);
+    void emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W);
+    void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc);
+
+    // graph replay
+    hipGraphExec_t graph_exec = nullptr;
+    hipStream_t cap_stream = nullptr;
+    bool graph_valid = false, warm = false;
+    const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false;
+};
+
+}  // namespace ldx

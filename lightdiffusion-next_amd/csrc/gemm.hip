@@ -1,0 +1,281 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950.
+//
+// Replaces, on the reference hot path, every F.linear (cond/cast.py:107) and conv (cast.py:174)
+// of UNetModel1 / VAE Decoder / CLIP: Linear, Conv2d 1x1, Conv2d 3x3 (stride 1|2, pad 1) and
+// Upsample1's nearest-resize + conv, with the bias / time-embedding add / GEGLU / residual-add
+// epilogues of ResBlock1._forward (ResBlock.py:315-335), BasicTransformerBlock._forward
+// (transformer.py:186-245) and SpatialTransformer.forward (transformer.py:342-377) fused in.
+//
+// Tiling: 128x128 output tile per 256-thread workgroup (4 waves, 2x2, 64x64 per wave as 4x4
+// MFMA 16x16x32 tiles), BK = 64, double-buffered LDS (2 x 32 KiB), register-staged global loads
+// issued one K-tile ahead (cdna guide T14) so the HBM/L2 latency hides under 32 MFMAs per wave.
+// LDS rows are 128 B (64 x 16-bit) with a 16-B-chunk XOR swizzle (chunk ^= row & 7), which makes
+// both the ds_write_b128 staging and the ds_read_b128 fragment reads bank-conflict free.
+// The MFMA is issued as D = W_frag x A_frag so each lane ends up with 4 consecutive output
+// channels of one output row -> 8-byte coalesced epilogue stores into the NHWC activation.
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+
+template <typename T, int MODE>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V8 = typename Vec<T>::v8;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l15 = lane & 15, g4 = lane >> 4;
+
+    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_m = (p.M + BM - 1) / BM;
+    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int tm = bid / tiles_n, tn = bid % tiles_n;
+    const int m0 = tm * BM, n0 = tn * BN;
+    const int nk = p.K / BK;
+
+    // ---- per-thread staging coordinates: 4 A chunks + 4 W chunks of 16 B per K-tile ----
+    const int srow = tid >> 3;        // 0..31 (+32*j)
+    const int schunk = tid & 7;       // 16-B chunk within the 128-B K-slice
+    const T* __restrict__ Ap = (const T*)p.A;
+    const T* __restrict__ Wp = (const T*)p.W;
+
+    long a_off[4];      // plain: row offset ; conv: batch base offset
+    int a_oy[4], a_ox[4];
+    bool a_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + srow + 32 * j;
+        a_ok[j] = m < p.M;
+        if (MODE == 0) {
+            a_off[j] = (long)m * p.lda + schunk * 8;
+            a_oy[j] = a_ox[j] = 0;
+        } else {
+            const int hw = p.Hout * p.Wout;
+            const int b = m / hw, rem = m - b * hw;
+            const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
+            a_off[j] = (long)b * p.Hin * p.Win * p.lda + schunk * 8;
+            a_oy[j] = oy * p.stride - 1;
+            a_ox[j] = ox * p.stride - 1;
+        }
+    }
+    long w_off[4];
+    bool w_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int n = n0 + srow + 32 * j;
+        w_ok[j] = n < p.N;
+        w_off[j] = (long)n * p.K + schunk * 8;
+    }
+    const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
+    const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
+
+    uint4 ra[4], rb[4];
+    int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
+    auto gload = [&](int kt) {
+        const int k0 = kt * BK;
+        if (MODE == 0) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                ra[j] = a_ok[j] ? *(const uint4*)(Ap + a_off[j] + k0) : make_uint4(0, 0, 0, 0);
+        } else {
+            const int ky = st_ky, kx = st_kx, ci0 = st_ci;   // running (tap, channel) state, no divides
+            st_ci += BK;
+            if (st_ci >= p.Cin) { st_ci = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
+                const bool ok = a_ok[j] && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
+                if (p.resize) {   // nearest: src = min(floor(dst * in/out), in-1)  (torch upsample_nearest)
+                    iy = min((int)floorf((float)iy * rs_y), p.Hin - 1);
+                    ix = min((int)floorf((float)ix * rs_x), p.Win - 1);
+                }
+                const long off = a_off[j] + ((long)iy * p.Win + ix) * p.lda + ci0;
+                ra[j] = ok ? *(const uint4*)(Ap + off) : make_uint4(0, 0, 0, 0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            rb[j] = w_ok[j] ? *(const uint4*)(Wp + w_off[j] + k0) : make_uint4(0, 0, 0, 0);
+    };
+    auto lstore = [&](int stage) {
+        char* sA = smem + stage * STAGE_BYTES;
+        char* sB = sA + BM * BK * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int row = srow + 32 * j;
+            const int off = row * 128 + ((schunk ^ (row & 7)) << 4);
+            *(uint4*)(sA + off) = ra[j];
+            *(uint4*)(sB + off) = rb[j];
+        }
+    };
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    gload(0);
+    lstore(0);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        const bool more = (kt + 1) < nk;
+        if (more) gload(kt + 1);
+        const char* sA = smem + cur * STAGE_BYTES;
+        const char* sB = sA + BM * BK * 2;
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            V8 af[4], bf[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int row = wm * 64 + i * 16 + l15;
+                const int ch = (ks * 4 + g4) ^ (row & 7);
+                af[i] = as_v8<T>(*(const uint4*)(sA + row * 128 + (ch << 4)));
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = wn * 64 + j * 16 + l15;
+                const int ch = (ks * 4 + g4) ^ (row & 7);
+                bf[j] = as_v8<T>(*(const uint4*)(sB + row * 128 + (ch << 4)));
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
+        }
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
+    const T* __restrict__ Rp = (const T*)p.R;
+    T* __restrict__ Cp = (T*)p.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + wm * 64 + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        if (!p.geglu) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + 4 * g4;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const bool full = (n + 3) < p.N;
+                if (full) {
+                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        float x = v[r];
+                        if (p.bias) x += p.bias[n + r];
+                        if (rv) x += rv[n + r];
+                        if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+                        if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
+                        if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
+                    }
+                }
+            }
+        } else {
+            // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int na = n0 + wn * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
+                const int ng = na + 32;                                // GEMM column of 'g'
+                if (ng >= p.N) continue;
+                const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
+                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                float g[4] = {acc[i][j + 2][0], acc[i][j + 2][1], acc[i][j + 2][2], acc[i][j + 2][3]};
+                if (p.bias) {
+                    const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+                }
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = a[r] * gelu_erf_f(g[r]);
+                if (Cp) *(uint2*)(Cp + (long)m * p.ldc + no) = pack4<T>(v[0], v[1], v[2], v[3]);
+                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+template <typename T>
+static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const size_t lds = 2 * STAGE_BYTES;
+    if (a.mode == 0) {
+        static bool attr0 = false;
+        if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
+        hipLaunchKernelGGL((gemm_kernel<T, 0>), dim3(tiles), dim3(256), lds, s, a);
+    } else {
+        static bool attr1 = false;
+        if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
+        hipLaunchKernelGGL((gemm_kernel<T, 1>), dim3(tiles), dim3(256), lds, s, a);
+    }
+}
+
+void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    if (dt == DT_BF16) launch_gemm_t<__bf16>(a, s); else launch_gemm_t<_Float16>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// Skinny GEMM (M <= 64): one wave per output column n, lanes stride K in 8-element chunks.
+template <typename T>
+__global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= p.N) return;
+    const T* __restrict__ w = (const T*)p.W + (long)n * p.K;
+    for (int mb = 0; mb < p.M; mb += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int k = lane * 8; k < p.K; k += 64 * 8) {
+            float wf[8];
+            unpack8<T>(*(const uint4*)(w + k), wf);
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const int m = mb + mi;
+                if (m < p.M) {
+                    const float* xr = p.x + (long)m * p.ldx + k;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        float xv = xr[e];
+                        if (p.in_act) xv = xv / (1.0f + expf(-xv));
+                        acc[mi] = fmaf(xv, wf[e], acc[mi]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+            const float v = wave_sum(acc[mi]);
+            const int m = mb + mi;
+            if (lane == 0 && m < p.M) {
+                float o = v + (p.bias ? p.bias[n] : 0.f);
+                if (p.out_act) o = o / (1.0f + expf(-o));
+                p.out[(long)m * p.ldo + n] = o;
+            }
+        }
+    }
+}
+
+void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) return;
+    dim3 grid((a.N + 3) / 4), block(256);
+    if (dt == DT_BF16) hipLaunchKernelGGL((skinny_kernel<__bf16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((skinny_kernel<_Float16>), grid, block, 0, s, a);
+}
+
+}  // namespace ldx

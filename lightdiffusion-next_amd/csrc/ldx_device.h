@@ -1,0 +1,89 @@
+// Device-side helpers shared by the gfx950 kernels (wave64, MFMA 16x16x32 16-bit inputs).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldx {
+
+typedef __attribute__((ext_vector_type(8))) __bf16   bf16x8;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16   bf16x4;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
+typedef __attribute__((ext_vector_type(4))) float    f32x4;
+
+template <typename T> struct Vec;
+template <> struct Vec<__bf16>   { using v8 = bf16x8; using v4 = bf16x4; };
+template <> struct Vec<_Float16> { using v8 = f16x8;  using v4 = f16x4; };
+
+// D(16x16 f32) += A(16x32) * B(32x16).  Lane l supplies A[i = l&15][k = 8*(l>>4) + 0..7] and
+// B[k = 8*(l>>4) + 0..7][j = l&15]; result lane l holds D[i = 4*(l>>4) + r][j = l&15], r = 0..3.
+__device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+union U128 {
+    uint4 u;
+    bf16x8 b;
+    f16x8 h;
+    uint2 d[2];
+};
+
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 as_v8(const uint4& u);
+template <> __device__ __forceinline__ bf16x8 as_v8<__bf16>(const uint4& u) { U128 x; x.u = u; return x.b; }
+template <> __device__ __forceinline__ f16x8 as_v8<_Float16>(const uint4& u) { U128 x; x.u = u; return x.h; }
+
+template <typename T> __device__ __forceinline__ float to_f32(T v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v) { return (T)v; }
+
+// unpack 8 16-bit values held in a uint4
+template <typename T> __device__ __forceinline__ void unpack8(const uint4& u, float (&f)[8]) {
+    typename Vec<T>::v8 v = as_v8<T>(u);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) f[i] = (float)v[i];
+}
+template <typename T> __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+    typename Vec<T>::v8 v;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (T)f[i];
+    union { typename Vec<T>::v8 v; uint4 u; } x; x.v = v; return x.u;
+}
+template <typename T> __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
+    typename Vec<T>::v4 v; v[0] = (T)a; v[1] = (T)b; v[2] = (T)c; v[3] = (T)d;
+    union { typename Vec<T>::v4 v; uint2 u; } x; x.v = v; return x.u;
+}
+template <typename T> __device__ __forceinline__ void unpack4(const uint2& u, float (&f)[4]) {
+    union { typename Vec<T>::v4 v; uint2 u; } x; x.u = u;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) f[i] = (float)x.v[i];
+}
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): give each XCD a contiguous
+// range of logical tiles so neighbouring tiles (sharing A/W panels) hit the same private L2.
+// Bijective for any grid size (cdna guide T1).
+__device__ __forceinline__ int xcd_remap(int bid, int nblk) {
+    const int nx = 8;
+    if (nblk < 2 * nx) return bid;
+    const int q = nblk / nx, r = nblk % nx;
+    const int xcd = bid % nx, idx = bid / nx;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + idx;
+}
+
+}  // namespace ldx

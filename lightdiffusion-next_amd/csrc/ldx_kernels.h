@@ -1,0 +1,117 @@
+// ldx — MI355X (gfx950 / CDNA4) kernels for the LightDiffusion-Next denoising hot path.
+// Internal header: argument structs + host launchers for every device kernel.
+// All activations are NHWC ("token-major") 16-bit (bf16 or fp16) with an explicit row stride
+// (ld*) so that channel-concatenation (reference: torch.cat([h, hs.pop()], 1), unet.py:750)
+// is a pointer offset, never a copy.  Accumulation, norm statistics and softmax are fp32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ldx {
+
+enum DType : int { DT_BF16 = 0, DT_F16 = 1 };
+
+// ---------------------------------------------------------------------------------------------
+// GEMM / implicit-GEMM convolution:  C[M][N] = epilogue( A[M][K] * W[N][K]^T )
+// mode 0: A is a plain row-major matrix (row stride lda), K % 64 == 0.
+// mode 1: A is an NHWC image [B][Hin][Win][lda]; 3x3 window, pad 1, stride 1|2, optional
+//         nearest-neighbour resize of the input to (Hv,Wv) fused into the gather
+//         (reference Upsample1: F.interpolate(nearest) then conv, ResBlock.py:75-138).
+//         K = 9*Cin with k = (ky*3+kx)*Cin + ci, Cin % 64 == 0.
+// Epilogue (all optional, applied in this order): + bias[n], + rowvec[(m / rows_per_batch)][n],
+//         GEGLU pairing (out = a * gelu_erf(g); reference cond/Activation.py:6-31),
+//         + R[m][n] residual, store 16-bit C (ldc) and/or fp32 Cf (ldcf).
+struct GemmArgs {
+    const void* A;  int lda;
+    const void* W;                 // [N][K] 16-bit, K contiguous
+    int M, N, K;
+    int mode;                      // 0 plain, 1 conv3x3
+    int Cin, Hin, Win;             // conv: stored input image
+    int Hv, Wv;                    // conv: virtual (resized) input extent seen by the 3x3 window
+    int Hout, Wout, stride;        // conv: output extent
+    int resize;                    // conv: 1 if (Hv,Wv) != (Hin,Win) -> nearest gather
+    const float* bias;             // [N] or null
+    const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
+    int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2
+    const void* R; int ldr;        // residual (16-bit) or null
+    void* C; int ldc;              // 16-bit output or null
+    float* Cf; int ldcf;           // fp32 output or null
+};
+void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
+
+// Skinny GEMM for tiny M (time embedding path): out[m][n] = bias[n] + sum_k act(x[m][k]) W[n][k]
+// x, out fp32; W 16-bit [N][K]; act: 0 none, 1 SiLU on the input (reference ResBlock emb_layers:
+// nn.SiLU() then Linear, ResBlock.py:283-295); out_act: 1 SiLU on the output (time_embed, unet.py:334-342).
+struct SkinnyArgs {
+    const float* x; int ldx; const void* W; const float* bias; float* out; int ldo;
+    int M, N, K; int in_act; int out_act;
+};
+void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Flash attention (online softmax): O[b][n][h*D+d] = softmax(q k^T * scale) v
+// q rows: Q + (b*Nq + n)*ldq + h*D ;  k/v rows: K + (b*Mk + m)*ldk + h*D  (same for V with ldv)
+// D % 8 == 0, D <= 160.  causal: 1 -> key m allowed iff m <= n (CLIP text encoder).
+struct AttnArgs {
+    const void* Q; int ldq; const void* K; int ldk; const void* V; int ldv;
+    void* O; int ldo;
+    int B, H, Nq, Mk, D; float scale; int causal;
+};
+void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// GroupNorm(32 groups) over NHWC + optional SiLU.  Two launches: partial statistics, then apply.
+struct GroupNormArgs {
+    const void* X; int ldx; void* Y; int ldy;
+    int B, HW, C, G; float eps; int silu;
+    const float* gamma; const float* beta;
+    float* partial;                // workspace [B][GN_NCHUNK][G][2]
+};
+constexpr int GN_NCHUNK = 32;
+void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s);
+
+// LayerNorm over the last dim C of [rows][ldx] -> [rows][ldy]
+struct LayerNormArgs {
+    const void* X; int ldx; void* Y; int ldy; int rows, C; float eps;
+    const float* gamma; const float* beta;
+};
+void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------
+// Edge / scheduler kernels (fp32 NCHW at the boundary, reference ModelBase.py:72-133).
+// prep: xc = x / sqrt(sigma^2 + 1) -> NHWC 16-bit with Cpad channels (zeros above C);
+//       t = argmin_k |ln sigma - log_sigmas[k]| ; temb_out[b][:] = temb_table[t][:]
+struct PrepArgs {
+    const float* x; const float* sigma; int B, C, H, W; int Cpad; void* xc;     // xc [B][H*W][Cpad]
+    const float* log_sigmas; int n_sigmas; const float* temb_table; int temb_dim;
+    float* temb_out; float* t_out;   // [B][temb_dim], [B]
+    int scale_input;                 // 1: divide by sqrt(sigma^2+1) ; 0: raw (ldx_unet_forward)
+    const float* t_in;               // if non-null: timestep indices given directly (no sigma lookup)
+};
+void launch_prep(const PrepArgs& a, DType dt, hipStream_t s);
+// finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)
+struct FinishArgs { const float* eps; int ld; const float* x; const float* sigma; float* out; int B, C, HW; };
+void launch_finish(const FinishArgs& a, hipStream_t s);
+
+// 16-bit <-> fp32 conversion helpers for tests / host plumbing
+void launch_f32_to_t(const float* in, void* out, size_t n, DType dt, hipStream_t s);
+void launch_t_to_f32(const void* in, float* out, size_t n, DType dt, hipStream_t s);
+// NCHW fp32 <-> NHWC 16-bit (VAE boundary)
+void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int Cpad, float scale, DType dt, hipStream_t s);
+
+// Sampler elementwise kernels (fp32, reference samplers.py / CFG.py):
+//  d = lerp(den_uncond, den_cond, cfg)                             (torch.lerp, CFG.py:60)
+//  kind 0 euler: x = x + ((x - d) / c0) * c1   c0 = sigma_hat, c1 = sigma_next - sigma_hat (samplers.py:308, util.py:26-37)
+//  kind 1 dpmpp: x = c0 * x - c1 * d           c0 = sigma_next/sigma, c1 = expm1(-h)       (samplers.py:945-946)
+//  kind 2      : denoised_out = d only (multiscale steps combine at low resolution first)
+// den_*: the two [B] chunks [uncond; cond] returned by the wrapper (cond.py:194-195 order).
+struct StepArgs {
+    float* x; const float* den_uncond; const float* den_cond; float* denoised_out;  // denoised_out optional
+    size_t n; float cfg; int kind;
+    float c0, c1;
+};
+void launch_sampler_step(const StepArgs& a, hipStream_t s);
+// bilinear resize (align_corners=False, antialias=False) of fp32 NCHW planes
+void launch_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s);
+
+}  // namespace ldx

@@ -1,0 +1,182 @@
+// Boundary and scheduler-side elementwise kernels (fp32 at the edge, 16-bit NHWC inside).
+//
+// prep   : BaseModel.apply_model's input half (Model/ModelBase.py:72-112): EPS.calculate_input
+//          (sample/sampling.py:29-35), ModelSamplingDiscrete.timestep (sampling.py:309-320) and the
+//          timestep_embedding lookup (sample/sampling_util.py:56-76, table built by the host).
+// finish : EPS.calculate_denoised (sampling.py:37-56).
+// sampler_step / bilinear : the per-iteration latent update of samplers.sample_euler
+//          (samplers.py:166-327) / sample_dpmpp_2m_cfgpp (samplers.py:754-962) incl. the CFG lerp
+//          of CFG.cfg_function (CFG.py:55-60) and the multiscale F.interpolate(bilinear).
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+template <typename T>
+__global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p) {
+    // one thread per (b, pixel, 8-channel chunk) of the padded NHWC output
+    const int HW = p.H * p.W;
+    const int cpp = p.Cpad / 8;
+    const long total = (long)p.B * HW * cpp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % cpp);
+        const long bp = idx / cpp;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        float scale = 1.f;
+        if (p.scale_input) { const float sg = p.sigma[b]; scale = 1.0f / sqrtf(sg * sg + 1.0f); }
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            f[e] = (c < p.C) ? p.x[((long)b * p.C + c) * HW + pix] * scale : 0.f;
+        }
+        *(uint4*)((T*)p.xc + ((long)b * HW + pix) * p.Cpad + ch * 8) = pack8<T>(f);
+    }
+}
+
+// one block per sample: nearest log-sigma table index (first minimum, like torch.argmin), then
+// copy the host-built sinusoidal embedding row.
+__global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    __shared__ int st;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (p.t_in) {
+        if (tid == 0) st = (int)p.t_in[b];
+    } else {
+        const float ls = logf(p.sigma[b]);
+        float best = INFINITY; int bi = 0x7fffffff;
+        for (int k = tid; k < p.n_sigmas; k += 256) {
+            const float d = fabsf(ls - p.log_sigmas[k]);
+            if (d < best) { best = d; bi = k; }
+        }
+        sd[tid] = best; si[tid] = bi;
+        __syncthreads();
+        for (int o = 128; o > 0; o >>= 1) {
+            if (tid < o) {
+                const float d2 = sd[tid + o]; const int i2 = si[tid + o];
+                if (d2 < sd[tid] || (d2 == sd[tid] && i2 < si[tid])) { sd[tid] = d2; si[tid] = i2; }
+            }
+            __syncthreads();
+        }
+        if (tid == 0) st = si[0];
+    }
+    __syncthreads();
+    int t = st;
+    t = max(0, min(t, p.n_sigmas - 1));
+    for (int j = tid; j < p.temb_dim; j += 256) p.temb_out[(long)b * p.temb_dim + j] = p.temb_table[(long)t * p.temb_dim + j];
+    if (tid == 0 && p.t_out) p.t_out[b] = (float)t;
+}
+
+void launch_prep(const PrepArgs& a, DType dt, hipStream_t s) {
+    const long total = (long)a.B * a.H * a.W * (a.Cpad / 8);
+    int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
+    if (dt == DT_BF16) hipLaunchKernelGGL((prep_image_kernel<__bf16>), dim3(grid), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((prep_image_kernel<_Float16>), dim3(grid), dim3(256), 0, s, a);
+    if (a.temb_out) hipLaunchKernelGGL(prep_time_kernel, dim3(a.B), dim3(256), 0, s, a);
+}
+
+__global__ __launch_bounds__(256) void finish_kernel(const FinishArgs p) {
+    const long total = (long)p.B * p.C * p.HW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int pix = (int)(idx % p.HW);
+        const long bc = idx / p.HW;
+        const int c = (int)(bc % p.C), b = (int)(bc / p.C);
+        const float e = p.eps[((long)b * p.HW + pix) * p.ld + c];
+        p.out[idx] = p.x ? (p.x[idx] - e * p.sigma[b]) : e;
+    }
+}
+void launch_finish(const FinishArgs& a, hipStream_t s) {
+    const long total = (long)a.B * a.C * a.HW;
+    int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(finish_kernel, dim3(grid), dim3(256), 0, s, a);
+}
+
+template <typename T>
+__global__ void f32_to_t_kernel(const float* in, T* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (T)in[i];
+}
+template <typename T>
+__global__ void t_to_f32_kernel(const T* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) out[i] = (float)in[i];
+}
+static int grid_for(size_t n) { size_t g = (n + 255) / 256; if (g > 8192) g = 8192; if (g < 1) g = 1; return (int)g; }
+void launch_f32_to_t(const float* in, void* out, size_t n, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL((f32_to_t_kernel<__bf16>), dim3(grid_for(n)), dim3(256), 0, s, in, (__bf16*)out, n);
+    else hipLaunchKernelGGL((f32_to_t_kernel<_Float16>), dim3(grid_for(n)), dim3(256), 0, s, in, (_Float16*)out, n);
+}
+void launch_t_to_f32(const void* in, float* out, size_t n, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL((t_to_f32_kernel<__bf16>), dim3(grid_for(n)), dim3(256), 0, s, (const __bf16*)in, out, n);
+    else hipLaunchKernelGGL((t_to_f32_kernel<_Float16>), dim3(grid_for(n)), dim3(256), 0, s, (const _Float16*)in, out, n);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* in, T* out, int B, int C, int HW, int Cpad, float scale) {
+    const int cpp = Cpad / 8;
+    const long total = (long)B * HW * cpp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % cpp);
+        const long bp = idx / cpp;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            f[e] = (c < C) ? in[((long)b * C + c) * HW + pix] * scale : 0.f;
+        }
+        *(uint4*)(out + ((long)b * HW + pix) * Cpad + ch * 8) = pack8<T>(f);
+    }
+}
+void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int Cpad, float scale, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * HW * (Cpad / 8);
+    if (dt == DT_BF16) hipLaunchKernelGGL((nchw_to_nhwc_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, in, (__bf16*)out, B, C, HW, Cpad, scale);
+    else hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, in, (_Float16*)out, B, C, HW, Cpad, scale);
+}
+
+#pragma clang fp contract(off)
+__global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs p) {
+    // Same operation order (and no FMA contraction) as the reference's fp32 tensor expressions.
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < p.n; i += (size_t)gridDim.x * 256) {
+        const float u = p.den_uncond[i], c = p.den_cond[i];
+        // torch.lerp(u, c, w): |w| < 0.5 ? u + w*(c-u) : c - (c-u)*(1-w)   (ATen Lerp.h)
+        const float diff = c - u;
+        const float d = (fabsf(p.cfg) < 0.5f) ? (u + p.cfg * diff) : (c - diff * (1.0f - p.cfg));
+        if (p.denoised_out) p.denoised_out[i] = d;
+        if (p.kind == 2) continue;                           // CFG combine only
+        const float x = p.x[i];
+        float xn;
+        if (p.kind == 0) xn = x + ((x - d) / p.c0) * p.c1;   // c0 = sigma_hat, c1 = sigma_next - sigma_hat
+        else xn = p.c0 * x - p.c1 * d;                       // c0 = sigma_next/sigma, c1 = expm1(-h)
+        p.x[i] = xn;
+    }
+}
+#pragma clang fp contract(fast)
+void launch_sampler_step(const StepArgs& a, hipStream_t s) {
+    hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a);
+}
+
+// torch upsample_bilinear2d, align_corners=False: src = max((dst + .5) * in/out - .5, 0)
+__global__ __launch_bounds__(256) void bilinear_kernel(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout) {
+    const float sy = (float)Hin / (float)Hout, sx = (float)Win / (float)Wout;
+    const long total = (long)planes * Hout * Wout;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ox = (int)(idx % Wout);
+        const long r = idx / Wout;
+        const int oy = (int)(r % Hout), pl = (int)(r / Hout);
+        const float fy = fmaxf(((float)oy + 0.5f) * sy - 0.5f, 0.f);
+        const float fx = fmaxf(((float)ox + 0.5f) * sx - 0.5f, 0.f);
+        const int y0 = (int)fy, x0 = (int)fx;
+        const int y1 = min(y0 + 1, Hin - 1), x1 = min(x0 + 1, Win - 1);
+        const float ly = fy - (float)y0, lx = fx - (float)x0;
+        const float* pin = in + (long)pl * Hin * Win;
+        const float v00 = pin[y0 * Win + x0], v01 = pin[y0 * Win + x1];
+        const float v10 = pin[y1 * Win + x0], v11 = pin[y1 * Win + x1];
+        out[idx] = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    }
+}
+void launch_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s) {
+    const size_t total = (size_t)planes * Hout * Wout;
+    hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, planes, Hin, Win, Hout, Wout);
+}
+
+}  // namespace ldx

@@ -1,0 +1,211 @@
+// GroupNorm(32)+SiLU and LayerNorm over NHWC 16-bit activations (HBM-bound kernels).
+//
+// Reference call sites: F.group_norm via cast.GroupNorm (cond/cast.py:224-257) in
+// ResBlock1.in_layers/out_layers (ResBlock.py:251-299, eps 1e-5), SpatialTransformer.norm
+// (transformer.py:286-293, eps 1e-6), UNet out (unet.py:663-677), VAE Normalize
+// (Attention/Attention.py:11-31, eps 1e-6); F.layer_norm via cast.LayerNorm (cast.py:260-290)
+// in BasicTransformerBlock (transformer.py:186-245) and CLIP (clip/Clip.py).
+//
+// NHWC makes a pixel's channels contiguous, so both kernels read/write full 16-byte chunks of
+// coalesced rows.  Each thread owns a fixed 8-channel chunk (tx) and strides over pixels (ty):
+// per-channel fp32 sum / sum-of-squares live in registers, are reduced through LDS in a fixed
+// order (deterministic, no atomics) and written as per-(batch, pixel-chunk, group) partials.
+// The apply kernel folds the partials into mean/rstd, pre-multiplies gamma/beta into one FMA per
+// element and fuses SiLU.  Statistics are fp32 over the exact 16-bit inputs.
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+struct GnGeom { int CH, TX, RY; };
+static inline GnGeom gn_geom(int C) {
+    const int cpp = C / 8;
+    int ch = 1;                                   // chunks per thread: 1, 2 or 4 (template instances)
+    while (ch < 4 && (cpp / ch > 256 || cpp % ch)) ch *= 2;
+    GnGeom g; g.CH = ch; g.TX = cpp / ch; g.RY = 256 / g.TX; if (g.RY < 1) g.RY = 1;
+    return g;
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs p, int TX, int RY) {
+    extern __shared__ float sred[];                 // [RY][C][2]
+    const int tid = threadIdx.x;
+    const int tx = tid % TX, ty = tid / TX;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const int per = (p.HW + GN_NCHUNK - 1) / GN_NCHUNK;
+    const int pb = chunk * per, pe = min(p.HW, pb + per);
+    const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx;
+
+    float s[CH][8], q[CH][8];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s[k][e] = 0.f; q[k][e] = 0.f; }
+
+    if (ty < RY) {
+        for (int pix = pb + ty; pix < pe; pix += RY) {
+#pragma unroll
+            for (int k = 0; k < CH; ++k) {
+                float f[8];
+                unpack8<T>(*(const uint4*)(X + (long)pix * p.ldx + (tx + TX * k) * 8), f);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { s[k][e] += f[e]; q[k][e] = fmaf(f[e], f[e], q[k][e]); }
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < CH; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int c = (tx + TX * k) * 8 + e;
+                sred[(ty * p.C + c) * 2 + 0] = s[k][e];
+                sred[(ty * p.C + c) * 2 + 1] = q[k][e];
+            }
+    }
+    __syncthreads();
+    if (tid < p.G * 2) {
+        const int g = tid >> 1, st = tid & 1;
+        const int cpg = p.C / p.G;
+        float acc = 0.f;
+        for (int r = 0; r < RY; ++r)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += sred[(r * p.C + c) * 2 + st];
+        p.partial[(((long)b * GN_NCHUNK + chunk) * p.G + g) * 2 + st] = acc;
+    }
+}
+
+template <typename T, int CH>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, int TX, int RY, int nblk) {
+    __shared__ float smean[64], srstd[64];
+    const int tid = threadIdx.x;
+    const int b = blockIdx.y;
+    const int cpg = p.C / p.G;
+    if (tid < p.G) {
+        float su = 0.f, sq = 0.f;
+        for (int ck = 0; ck < GN_NCHUNK; ++ck) {
+            const float* pp = p.partial + (((long)b * GN_NCHUNK + ck) * p.G + tid) * 2;
+            su += pp[0]; sq += pp[1];
+        }
+        const float n = (float)p.HW * (float)cpg;
+        const float mean = su / n;
+        const float var = fmaxf(sq / n - mean * mean, 0.f);
+        smean[tid] = mean;
+        srstd[tid] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int tx = tid % TX, ty = tid / TX;
+    if (ty >= RY) return;
+    float sc[CH][8], sh[CH][8];
+#pragma unroll
+    for (int k = 0; k < CH; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = (tx + TX * k) * 8 + e;
+            const int g = c / cpg;
+            const float a = srstd[g] * p.gamma[c];
+            sc[k][e] = a;
+            sh[k][e] = p.beta[c] - smean[g] * a;
+        }
+    const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx;
+    T* __restrict__ Y = (T*)p.Y + (long)b * p.HW * p.ldy;
+    const int per = (p.HW + nblk - 1) / nblk;
+    const int pb = blockIdx.x * per, pe = min(p.HW, pb + per);
+    for (int pix = pb + ty; pix < pe; pix += RY) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            float f[8];
+            unpack8<T>(*(const uint4*)(X + (long)pix * p.ldx + (tx + TX * k) * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float y = fmaf(f[e], sc[k][e], sh[k][e]);
+                if (p.silu) y = silu_f(y);
+                f[e] = y;
+            }
+            *(uint4*)(Y + (long)pix * p.ldy + (tx + TX * k) * 8) = pack8<T>(f);
+        }
+    }
+}
+
+template <typename T>
+static void launch_gn_t(const GroupNormArgs& a, hipStream_t s) {
+    const GnGeom g = gn_geom(a.C);
+    dim3 grid1(GN_NCHUNK, a.B);
+    const size_t lds = (size_t)g.RY * a.C * 2 * sizeof(float);
+    int nblk = (a.HW + g.RY * 8 - 1) / (g.RY * 8);
+    if (nblk > 512) nblk = 512;
+    if (nblk < 1) nblk = 1;
+    dim3 grid2(nblk, a.B);
+    switch (g.CH) {
+        case 1:
+            hipLaunchKernelGGL((gn_stats_kernel<T, 1>), grid1, dim3(256), lds, s, a, g.TX, g.RY);
+            hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk);
+            break;
+        case 2:
+            hipLaunchKernelGGL((gn_stats_kernel<T, 2>), grid1, dim3(256), lds, s, a, g.TX, g.RY);
+            hipLaunchKernelGGL((gn_apply_kernel<T, 2>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk);
+            break;
+        default:
+            hipLaunchKernelGGL((gn_stats_kernel<T, 4>), grid1, dim3(256), lds, s, a, g.TX, g.RY);
+            hipLaunchKernelGGL((gn_apply_kernel<T, 4>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk);
+            break;
+    }
+}
+
+void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) launch_gn_t<__bf16>(a, s); else launch_gn_t<_Float16>(a, s);
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm: one wave per row, row held in registers (C <= 2048), two-pass mean / variance.
+template <typename T>
+__global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.rows) return;
+    const int nch = p.C >> 3;
+    const T* __restrict__ x = (const T*)p.X + row * p.ldx;
+    T* __restrict__ y = (T*)p.Y + row * p.ldy;
+    float f[4][8];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            unpack8<T>(*(const uint4*)(x + ch * 8), f[i]);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sum += f[i][e];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.C;
+    float vs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; vs = fmaf(d, d, vs); }
+        }
+    }
+    const float rstd = rsqrtf(wave_sum(vs) / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+            float o[8];
+            const float4 g0 = *(const float4*)(p.gamma + ch * 8), g1 = *(const float4*)(p.gamma + ch * 8 + 4);
+            const float4 b0 = *(const float4*)(p.beta + ch * 8), b1 = *(const float4*)(p.beta + ch * 8 + 4);
+            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gg[e] + bb[e];
+            *(uint4*)(y + ch * 8) = pack8<T>(o);
+        }
+    }
+}
+
+void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s) {
+    if (a.rows <= 0) return;
+    dim3 grid((a.rows + 3) / 4), block(256);
+    if (dt == DT_BF16) hipLaunchKernelGGL((ln_kernel<__bf16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((ln_kernel<_Float16>), grid, block, 0, s, a);
+}
+
+}  // namespace ldx

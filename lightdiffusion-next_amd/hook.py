@@ -1,0 +1,47 @@
+"""LdxUNetPatch — the drop-in object for model_options["model_function_wrapper"].
+
+The reference calls it at src/cond/cond.py:254-263 as
+    wrapper(model.apply_model, {"input": x[2B,4,h,w] fp32, "timestep": sigma[2B], "c": {...},
+                                "cond_or_uncond": [1, 0]}).chunk(batch_chunks)
+and installs it with ModelPatcher.set_model_unet_function_wrapper (src/Model/ModelPatcher.py:138-144).
+Same lifecycle contract as the reference's own accelerators, StableFastPatch
+(src/StableFast/StableFast.py:230-261) and the FBCache closure (src/WaveSpeed/fbcache_nodes.py:96-111):
+callable(model_function, params) -> denoised, `.to(device)` returns self (ModelPatcher.py:165-175
+replaces the option with the return value), deep-copy safe (ModelPatcher.clone deep-copies
+model_options, ModelPatcher.py:108).
+"""
+import torch
+
+from .engine import UNetEngine
+from .weights import UNetConfig
+
+
+class LdxUNetPatch:
+    def __init__(self, engine: UNetEngine):
+        self.engine = engine
+
+    @classmethod
+    def from_state_dict(cls, state_dict, cfg: UNetConfig = None, device: int = 0, dtype: str = "bf16"):
+        """Snapshot weights once (after ModelPatcher.patch_model, i.e. LoRA already merged: SURVEY §8b)."""
+        return cls(UNetEngine(cfg or UNetConfig.sd15(), state_dict, device=device, dtype=dtype))
+
+    def __call__(self, model_function, params):
+        x = params["input"]
+        sigma = params["timestep"]
+        c = params["c"]
+        ctx = c.get("c_crossattn")
+        if ctx is None:
+            raise ValueError("LdxUNetPatch: c['c_crossattn'] is required (SD1.5 cross-attention context)")
+        for k in ("c_concat", "control", "y"):
+            if c.get(k) is not None:
+                raise NotImplementedError(f"LdxUNetPatch: conditioning '{k}' is outside the SD1.5 hot path")
+        src_device = x.device
+        dev = self.engine.device
+        out = self.engine.denoise(x.to(dev, torch.float32), sigma.to(dev, torch.float32), ctx.to(dev, torch.float32))
+        return out if src_device == dev else out.to(src_device)
+
+    def to(self, device):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self      # the native engine is shared, never duplicated

@@ -1,0 +1,333 @@
+"""Host-side mirror of the reference's scheduler loop (src/sample/*, src/cond/cond.py) driving libldx.
+
+Same names, argument meaning and quirks as the reference so parity tests read like
+reference code:
+  ModelSamplingDiscrete       src/sample/sampling.py:221-356
+  calculate_sigmas & friends  src/sample/ksampler_util.py:152-271, sampling_util.py:106-125
+  prepare_noise               src/sample/ksampler_util.py:274-311   (CPU RNG, identical stream)
+  calc_cond_batch             src/cond/cond.py:150-288               ([uncond; cond] batch, lcm-padded ctx)
+  cfg / sampling_function     src/sample/CFG.py:6-161
+  sample_euler                src/sample/samplers.py:166-327         (incl. multiscale)
+  sample_dpmpp_2m_cfgpp       src/sample/samplers.py:754-962         (degenerates to 1st-order DPM++, A-2)
+  KSampler.sample / sample1   src/sample/sampling.py:773-1045        (multiscale whitelist quirk, A-3)
+Latents stay on the GPU in fp32; the per-step update runs in the HIP kernels behind ldx_sampler_step /
+ldx_bilinear.  Only Python scalars (sigmas) live on the host.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import lib
+from .engine import sd15_sigmas
+
+
+# ------------------------------------------------------------------------------------------------------
+class ModelSamplingDiscrete:
+    """sampling.py:221-356 for the SD1.5 'linear' schedule + EPS (sampling.py:26-97)."""
+
+    sigma_data = 1.0
+
+    def __init__(self):
+        self.sigmas, self.log_sigmas = sd15_sigmas()
+
+    @property
+    def sigma_min(self):
+        return self.sigmas[0]
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def timestep(self, sigma):
+        log_sigma = sigma.log()
+        dists = log_sigma - self.log_sigmas[:, None]
+        return dists.abs().argmin(dim=0).view(sigma.shape)
+
+    def sigma(self, timestep):
+        t = torch.clamp(timestep.float(), min=0, max=(len(self.sigmas) - 1))
+        low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+        log_sigma = (1 - w) * self.log_sigmas[low_idx] + w * self.log_sigmas[high_idx]
+        return log_sigma.exp()
+
+
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho = sigma_min ** (1 / rho)
+    max_inv_rho = sigma_max ** (1 / rho)
+    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return torch.cat([sigmas, sigmas.new_zeros([1])])
+
+
+def normal_scheduler(ms, steps):
+    start, end = ms.timestep(ms.sigma_max), ms.timestep(ms.sigma_min)
+    timesteps = torch.linspace(start, end, steps)
+    sigs = [ms.sigma(timesteps[x]) for x in range(len(timesteps))]
+    sigs += [0.0]
+    return torch.FloatTensor(sigs)
+
+
+def simple_scheduler(ms, steps):
+    sigs = []
+    ss = len(ms.sigmas) / steps
+    for x in range(steps):
+        sigs += [float(ms.sigmas[-(1 + int(x * ss))])]
+    sigs += [0.0]
+    return torch.FloatTensor(sigs)
+
+
+def beta_scheduler(ms, steps, alpha=0.6, beta=0.6):
+    import scipy.stats
+
+    total_timesteps = len(ms.sigmas) - 1
+    ts_normalized = np.linspace(0, 1, steps, endpoint=False)
+    ts_beta = scipy.stats.beta.ppf(1 - ts_normalized, alpha, beta)
+    ts_indices = np.rint(ts_beta * total_timesteps).astype(np.int32)
+    unique_ts, indices = np.unique(ts_indices, return_index=True)
+    ordered_unique_ts = unique_ts[np.argsort(indices)]
+    sigs = [float(ms.sigmas[idx]) for idx in ordered_unique_ts]
+    sigs.append(0.0)
+    return torch.FloatTensor(sigs)
+
+
+def calculate_sigmas(ms, scheduler_name, steps):
+    if scheduler_name == "karras":
+        return get_sigmas_karras(n=steps, sigma_min=float(ms.sigma_min), sigma_max=float(ms.sigma_max))
+    if scheduler_name == "normal":
+        return normal_scheduler(ms, steps)
+    if scheduler_name == "simple":
+        return simple_scheduler(ms, steps)
+    if scheduler_name == "beta":
+        return beta_scheduler(ms, steps)
+    raise ValueError(f"invalid scheduler {scheduler_name}")
+
+
+def sigmas_for(ms, scheduler, steps, denoise=None):
+    """sample1's sigma selection incl. the denoise<1 truncation (sampling.py:966-985)."""
+    if denoise is None or denoise > 0.9999:
+        return calculate_sigmas(ms, scheduler, steps)
+    if denoise <= 0.0:
+        return torch.FloatTensor([])
+    new_steps = int(steps / denoise)
+    return calculate_sigmas(ms, scheduler, new_steps)[-(steps + 1):]
+
+
+def prepare_noise(latent_image, seed):
+    generator = torch.manual_seed(seed)
+    return torch.randn(latent_image.size(), dtype=latent_image.dtype, layout=latent_image.layout,
+                       generator=generator, device="cpu")
+
+
+# ------------------------------------------------------------------------------------------------------
+def _lcm_pad_contexts(conds):
+    """CONDCrossAttn.concat (cond.py:100-126): shorter prompts are REPEATED up to the lcm length."""
+    lens = [c.shape[1] for c in conds]
+    if all(length == lens[0] for length in lens):
+        return conds
+    target = lens[0]
+    for length in lens[1:]:
+        target = target * length // math.gcd(target, length)
+    return [c.repeat(1, target // c.shape[1], 1) if c.shape[1] < target else c for c in conds]
+
+
+class CFGDenoiser:
+    """CFGGuider.predict_noise -> sampling_function -> calc_cond_batch -> wrapper hook
+    (CFG.py:86-234, cond.py:150-288) for one positive and one negative full-area prompt.
+
+    Batch order is [uncond x B ; cond x B] (cond_or_uncond == [1, 0], cond.py:194-195)."""
+
+    def __init__(self, engine, positive, negative, cfg, batch, h, w, disable_cfg1_optimization=False):
+        self.engine, self.cfg = engine, float(cfg)
+        dev = engine.device
+        self.skip_uncond = math.isclose(self.cfg, 1.0) and not disable_cfg1_optimization
+        pos = positive.to(dev, torch.float32)
+        neg = negative.to(dev, torch.float32)
+        pos = pos.expand(batch, -1, -1) if pos.shape[0] == 1 else pos
+        neg = neg.expand(batch, -1, -1) if neg.shape[0] == 1 else neg
+        if self.skip_uncond:
+            self.ctx = pos.contiguous()
+            self.nb = batch
+        else:
+            neg, pos = _lcm_pad_contexts([neg, pos])
+            self.ctx = torch.cat([neg, pos]).contiguous()
+            self.nb = 2 * batch
+        self.batch = batch
+        self._bufs = {}
+
+    def _buffers(self, shape):
+        key = tuple(shape)
+        if key not in self._bufs:
+            b, c, h, w = shape
+            dev = self.engine.device
+            self._bufs[key] = (torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32),
+                               torch.empty((self.nb,), device=dev, dtype=torch.float32),
+                               torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32))
+        return self._bufs[key]
+
+    def __call__(self, x, sigma):
+        """Returns (denoised_uncond, denoised_cond) views, each [B,4,h,w] fp32."""
+        xin, sig, out = self._buffers(x.shape)
+        b = self.batch
+        xin[:b].copy_(x)
+        if not self.skip_uncond:
+            xin[b:].copy_(x)
+        sig.fill_(float(sigma))
+        self.engine.denoise(xin, sig, self.ctx, out=out)
+        if self.skip_uncond:
+            return out, out
+        return out[:b], out[b:]
+
+
+def _step(kind, x, du, dc, cfg, c0, c1, denoised_out=None):
+    L = lib.load()
+    lib.check(L.ldx_sampler_step(kind, lib.ptr(x), lib.ptr(du), lib.ptr(dc), lib.ptr(denoised_out),
+                                 x.numel(), float(cfg), float(c0), float(c1), lib.current_stream_ptr()),
+              "ldx_sampler_step")
+
+
+def _bilinear(t, size):
+    L = lib.load()
+    b, c, h, w = t.shape
+    out = torch.empty((b, c, size[0], size[1]), device=t.device, dtype=torch.float32)
+    lib.check(L.ldx_bilinear(lib.ptr(t.contiguous()), lib.ptr(out), b * c, h, w, size[0], size[1],
+                             lib.current_stream_ptr()), "ldx_bilinear")
+    return out
+
+
+class _Multiscale:
+    """The multi-scale bookkeeping shared by sample_euler / sample_dpmpp_2m_cfgpp
+    (samplers.py:190-263 and 780-848)."""
+
+    def __init__(self, shape, n_steps, enable, factor, fullres_start, fullres_end, intermittent):
+        _, _, self.orig_h, self.orig_w = shape
+        if enable and not (0.1 <= factor <= 1.0):
+            enable = False
+        if enable and (fullres_start < 0 or fullres_end < 0):
+            enable = False
+        self.scale_h = int(max(8, ((self.orig_h * factor) // 8) * 8)) if enable else self.orig_h
+        self.scale_w = int(max(8, ((self.orig_w * factor) // 8) * 8)) if enable else self.orig_w
+        self.active = enable and (self.scale_h != self.orig_h or self.scale_w != self.orig_w)
+        self.n_steps, self.start, self.end, self.intermittent = n_steps, fullres_start, fullres_end, intermittent
+
+    def fullres(self, step):
+        if not self.active:
+            return True
+        if step < self.start or step >= self.n_steps - self.end:
+            return True
+        if self.intermittent:
+            lo, hi = self.start, self.n_steps - self.end
+            if lo <= step < hi:
+                return (step - lo) % 2 == 0
+        return False
+
+
+@torch.no_grad()
+def sample_euler(model, x, sigmas, enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3,
+                 multiscale_fullres_end=8, multiscale_intermittent_fullres=False, trace=None):
+    """samplers.sample_euler (samplers.py:166-327) with s_churn = 0.  `model(x, sigma)` -> (uncond, cond)."""
+    n_steps = len(sigmas) - 1
+    ms = _Multiscale(x.shape, n_steps, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                     multiscale_fullres_end, multiscale_intermittent_fullres)
+    for i in range(n_steps):
+        sigma_hat = sigmas[i]
+        dt = sigmas[i + 1] - sigma_hat              # fp32 tensor scalars, like the reference
+        if ms.fullres(i):
+            du, dc = model(x, sigma_hat)
+            if trace is not None:
+                trace.append(tuple(x.shape[-2:]))
+            _step(0, x, du, dc, model.cfg, sigma_hat, dt)
+        else:
+            xs = _bilinear(x, (ms.scale_h, ms.scale_w))
+            if trace is not None:
+                trace.append(tuple(xs.shape[-2:]))
+            du, dc = model(xs, sigma_hat)
+            d = torch.empty_like(xs)
+            _step(2, xs, du, dc, model.cfg, 0.0, 0.0, denoised_out=d)
+            d = _bilinear(d, (ms.orig_h, ms.orig_w))
+            _step(0, x, d, d, 1.0, sigma_hat, dt)
+    return x
+
+
+@torch.no_grad()
+def sample_dpmpp_2m_cfgpp(model, x, sigmas, enable_multiscale=True, multiscale_factor=0.5,
+                          multiscale_fullres_start=5, multiscale_fullres_end=8,
+                          multiscale_intermittent_fullres=True, trace=None):
+    """samplers.sample_dpmpp_2m_cfgpp (samplers.py:754-962).  The CFG++/momentum branch never executes in
+    the reference, so every step is  x = (s'/s) x - expm1(-h) * denoised."""
+    n_steps = len(sigmas) - 1
+    ms = _Multiscale(x.shape, n_steps, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                     multiscale_fullres_end, multiscale_intermittent_fullres)
+    t_steps = -torch.log(sigmas)
+    sigma_steps = torch.exp(-t_steps)
+    ratios = sigma_steps[1:] / sigma_steps[:-1]
+    h_steps = t_steps[1:] - t_steps[:-1]
+    for i in range(n_steps):
+        h_expm1 = torch.expm1(-h_steps[i])
+        if ms.fullres(i):
+            du, dc = model(x, sigmas[i])
+            if trace is not None:
+                trace.append(tuple(x.shape[-2:]))
+            _step(1, x, du, dc, model.cfg, ratios[i], h_expm1)
+        else:
+            xs = _bilinear(x, (ms.scale_h, ms.scale_w))
+            if trace is not None:
+                trace.append(tuple(xs.shape[-2:]))
+            du, dc = model(xs, sigmas[i])
+            d = torch.empty_like(xs)
+            _step(2, xs, du, dc, model.cfg, 0.0, 0.0, denoised_out=d)
+            d = _bilinear(d, (ms.orig_h, ms.orig_w))
+            _step(1, x, d, d, 1.0, ratios[i], h_expm1)
+    return x
+
+
+_MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
+
+
+def _resolve_sampler(sampler_name):
+    """sampling.ksampler (sampling.py:500-534): only four names are recognised, the rest fall back to Euler."""
+    if sampler_name == "dpmpp_2m_cfgpp":
+        return sample_dpmpp_2m_cfgpp, True
+    if sampler_name in ("euler_ancestral_cfgpp", "dpmpp_sde_cfgpp", "euler_cfgpp"):
+        raise NotImplementedError(f"sampler '{sampler_name}' draws device-side noise / dy steps; next row (SURVEY §8 a5)")
+    return sample_euler, False
+
+
+class KSampler:
+    """KSampler.sample -> common_ksampler -> sample1 -> CFGGuider.sample (sampling.py:773-1233, CFG.py:164-357)
+    for txt2img / img2img latents with one positive and one negative prompt."""
+
+    def __init__(self, engine):
+        self.engine = engine
+        self.model_sampling = ModelSamplingDiscrete()
+
+    def sample(self, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent_image, denoise=1.0,
+               enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3,
+               multiscale_fullres_end=8, multiscale_intermittent_fullres=False, noise=None, trace=None):
+        ms = self.model_sampling
+        denoise = denoise or 1.0                                   # sampling.py:875 quirk (A-12)
+        latent_image = latent_image.float()
+        if noise is None:
+            noise = prepare_noise(latent_image, seed)
+        sigmas = sigmas_for(ms, scheduler, steps, denoise)
+        fn, disable_cfg1 = _resolve_sampler(sampler_name)
+        extra = {}
+        if sampler_name in _MULTISCALE_WHITELIST:                  # whitelist mismatch quirk (A-3)
+            extra = dict(enable_multiscale=enable_multiscale, multiscale_factor=multiscale_factor,
+                         multiscale_fullres_start=multiscale_fullres_start,
+                         multiscale_fullres_end=multiscale_fullres_end,
+                         multiscale_intermittent_fullres=multiscale_intermittent_fullres)
+        dev = self.engine.device
+        b, _, h, w = latent_image.shape
+        # CFGGuider.inner_sample (CFG.py:266-269): an all-zero latent is not shifted
+        if torch.count_nonzero(latent_image) > 0:
+            latent_image = latent_image * 0.18215                  # process_latent_in (Latent.py:19-39)
+        # KSAMPLER.sample noise scaling (sampling.py:58-83, 410-422)
+        max_sigma, s0 = float(ms.sigma_max), float(sigmas[0])
+        if math.isclose(max_sigma, s0, rel_tol=1e-05) or s0 > max_sigma:
+            x = noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)
+        else:
+            x = noise * sigmas[0]
+        x = (x + latent_image).to(dev)
+        model = CFGDenoiser(self.engine, positive, negative, cfg, b, h, w, disable_cfg1_optimization=disable_cfg1)
+        x = fn(model, x, sigmas, trace=trace, **extra)
+        return x / 0.18215                                         # process_latent_out (CFG.py:294)

@@ -1,0 +1,174 @@
+"""SD1.5-layout UNet state dict: key/shape inventory and seeded synthetic weights.
+
+No checkpoint exists offline, so parity fixtures and benchmarks use synthetic weights
+written into the *exact* key layout the reference builds in UNetModel1.__init__
+(src/NeuralNetwork/unet.py:333-677; canonical SD1.5 config = SURVEY.md Appendix B: 686 keys,
+859 520 964 parameters).  The inventory below is derived from the config alone, so it can be checked
+against the reference module's own state_dict (oracle/ref_capture.py does, strictly).
+"""
+import math
+import zlib
+from dataclasses import dataclass, field
+from typing import Dict, List, Tuple
+
+import torch
+
+
+@dataclass
+class UNetConfig:
+    """Keyword arguments of UNetModel1 that the SD1.5 family uses (unet.py:208-252, SD15.py:17-28)."""
+
+    in_channels: int = 4
+    out_channels: int = 4
+    model_channels: int = 320
+    channel_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: Tuple[int, ...] = (2, 2, 2, 2)
+    transformer_depth: Tuple[int, ...] = (1, 1, 1, 1, 1, 1, 0, 0)
+    transformer_depth_output: Tuple[int, ...] = (1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0)
+    transformer_depth_middle: int = 1
+    num_heads: int = 8
+    context_dim: int = 768
+
+    @staticmethod
+    def sd15() -> "UNetConfig":
+        return UNetConfig()
+
+    @staticmethod
+    def tiny(model_channels: int = 64, context_dim: int = 128) -> "UNetConfig":
+        """Same topology as SD1.5, narrower: head dims 8/16/32 at model_channels=64."""
+        return UNetConfig(model_channels=model_channels, context_dim=context_dim)
+
+    def reference_kwargs(self) -> dict:
+        """The dict SURVEY.md Appendix B feeds to SD15.sm_SD15 / UNetModel1."""
+        return dict(
+            use_checkpoint=False, image_size=32, use_spatial_transformer=True, legacy=False,
+            adm_in_channels=None, in_channels=self.in_channels, out_channels=self.out_channels,
+            model_channels=self.model_channels, num_res_blocks=list(self.num_res_blocks),
+            transformer_depth=list(self.transformer_depth),
+            transformer_depth_output=list(self.transformer_depth_output),
+            channel_mult=list(self.channel_mult), transformer_depth_middle=self.transformer_depth_middle,
+            use_linear_in_transformer=False, context_dim=self.context_dim,
+            use_temporal_resblock=False, use_temporal_attention=False,
+        )
+
+
+def _res(spec, pre, cin, cout, ted):
+    spec += [(f"{pre}.in_layers.0.weight", (cin,)), (f"{pre}.in_layers.0.bias", (cin,)),
+             (f"{pre}.in_layers.2.weight", (cout, cin, 3, 3)), (f"{pre}.in_layers.2.bias", (cout,)),
+             (f"{pre}.emb_layers.1.weight", (cout, ted)), (f"{pre}.emb_layers.1.bias", (cout,)),
+             (f"{pre}.out_layers.0.weight", (cout,)), (f"{pre}.out_layers.0.bias", (cout,)),
+             (f"{pre}.out_layers.3.weight", (cout, cout, 3, 3)), (f"{pre}.out_layers.3.bias", (cout,))]
+    if cin != cout:
+        spec += [(f"{pre}.skip_connection.weight", (cout, cin, 1, 1)), (f"{pre}.skip_connection.bias", (cout,))]
+
+
+def _xf(spec, pre, c, depth, ctx):
+    spec += [(f"{pre}.norm.weight", (c,)), (f"{pre}.norm.bias", (c,)),
+             (f"{pre}.proj_in.weight", (c, c, 1, 1)), (f"{pre}.proj_in.bias", (c,))]
+    for d in range(depth):
+        b = f"{pre}.transformer_blocks.{d}"
+        spec += [(f"{b}.attn1.to_q.weight", (c, c)), (f"{b}.attn1.to_k.weight", (c, c)),
+                 (f"{b}.attn1.to_v.weight", (c, c)),
+                 (f"{b}.attn1.to_out.0.weight", (c, c)), (f"{b}.attn1.to_out.0.bias", (c,)),
+                 (f"{b}.ff.net.0.proj.weight", (8 * c, c)), (f"{b}.ff.net.0.proj.bias", (8 * c,)),
+                 (f"{b}.ff.net.2.weight", (c, 4 * c)), (f"{b}.ff.net.2.bias", (c,)),
+                 (f"{b}.attn2.to_q.weight", (c, c)), (f"{b}.attn2.to_k.weight", (c, ctx)),
+                 (f"{b}.attn2.to_v.weight", (c, ctx)),
+                 (f"{b}.attn2.to_out.0.weight", (c, c)), (f"{b}.attn2.to_out.0.bias", (c,)),
+                 (f"{b}.norm1.weight", (c,)), (f"{b}.norm1.bias", (c,)),
+                 (f"{b}.norm2.weight", (c,)), (f"{b}.norm2.bias", (c,)),
+                 (f"{b}.norm3.weight", (c,)), (f"{b}.norm3.bias", (c,))]
+    spec += [(f"{pre}.proj_out.weight", (c, c, 1, 1)), (f"{pre}.proj_out.bias", (c,))]
+
+
+def unet_state_dict_spec(cfg: UNetConfig) -> List[Tuple[str, Tuple[int, ...]]]:
+    """(key, shape) for every tensor, walking the structure like UNetModel1.__init__ (unet.py:333-677)."""
+    mc, ted, ctx = cfg.model_channels, 4 * cfg.model_channels, cfg.context_dim
+    spec: List[Tuple[str, Tuple[int, ...]]] = [
+        ("time_embed.0.weight", (ted, mc)), ("time_embed.0.bias", (ted,)),
+        ("time_embed.2.weight", (ted, ted)), ("time_embed.2.bias", (ted,)),
+        ("input_blocks.0.0.weight", (mc, cfg.in_channels, 3, 3)), ("input_blocks.0.0.bias", (mc,)),
+    ]
+    td = list(cfg.transformer_depth)
+    tdo = list(cfg.transformer_depth_output)
+    ch, ib, chans = mc, 1, [mc]
+    nl = len(cfg.channel_mult)
+    for level, mult in enumerate(cfg.channel_mult):
+        for _ in range(cfg.num_res_blocks[level]):
+            _res(spec, f"input_blocks.{ib}.0", ch, mult * mc, ted)
+            ch = mult * mc
+            depth = td.pop(0)
+            if depth > 0:
+                _xf(spec, f"input_blocks.{ib}.1", ch, depth, ctx)
+            chans.append(ch)
+            ib += 1
+        if level != nl - 1:
+            spec += [(f"input_blocks.{ib}.0.op.weight", (ch, ch, 3, 3)), (f"input_blocks.{ib}.0.op.bias", (ch,))]
+            chans.append(ch)
+            ib += 1
+    _res(spec, "middle_block.0", ch, ch, ted)
+    if cfg.transformer_depth_middle >= 0:
+        _xf(spec, "middle_block.1", ch, cfg.transformer_depth_middle, ctx)
+        _res(spec, "middle_block.2", ch, ch, ted)
+    ob = 0
+    for level in reversed(range(nl)):
+        mult = cfg.channel_mult[level]
+        for i in range(cfg.num_res_blocks[level] + 1):
+            ich = chans.pop()
+            _res(spec, f"output_blocks.{ob}.0", ch + ich, mc * mult, ted)
+            ch = mc * mult
+            sub = 1
+            depth = tdo.pop()
+            if depth > 0:
+                _xf(spec, f"output_blocks.{ob}.1", ch, depth, ctx)
+                sub += 1
+            if level and i == cfg.num_res_blocks[level]:
+                spec += [(f"output_blocks.{ob}.{sub}.conv.weight", (ch, ch, 3, 3)),
+                         (f"output_blocks.{ob}.{sub}.conv.bias", (ch,))]
+            ob += 1
+    spec += [("out.0.weight", (ch,)), ("out.0.bias", (ch,)),
+             ("out.2.weight", (cfg.out_channels, mc, 3, 3)), ("out.2.bias", (cfg.out_channels,))]
+    return spec
+
+
+def _is_norm_weight(key: str) -> bool:
+    parts = key.split(".")
+    if parts[-1] != "weight":
+        return False
+    name = ".".join(parts[:-1])
+    return (name.endswith("in_layers.0") or name.endswith("out_layers.0") or name.endswith(".norm")
+            or name.endswith("norm1") or name.endswith("norm2") or name.endswith("norm3")
+            or name == "out.0" or name.endswith("layer_norm1") or name.endswith("layer_norm2")
+            or name.endswith("final_layer_norm") or ("norm" in parts[-2]))
+
+
+def synth_tensor(key: str, shape, seed: int, dtype=torch.float16) -> torch.Tensor:
+    """Deterministic per-key fill (independent of iteration order): biases ~N(0,.02), norm scales
+    1+N(0,.02), everything else N(0, 1/fan_in) — variance-preserving so activations stay O(1)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed((seed * 1000003 + zlib.crc32(key.encode())) & 0x7FFFFFFF)
+    n = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
+    if key.endswith(".bias"):
+        t = 0.02 * n
+    elif _is_norm_weight(key):
+        t = 1.0 + 0.02 * n
+    else:
+        fan_in = 1
+        for s in shape[1:]:
+            fan_in *= s
+        t = n / math.sqrt(max(fan_in, 1))
+    return t.to(dtype)
+
+
+def synth_state_dict(spec, seed: int = 1234, dtype=torch.float16) -> Dict[str, torch.Tensor]:
+    return {k: synth_tensor(k, s, seed, dtype) for k, s in spec}
+
+
+def param_count(spec) -> int:
+    n = 0
+    for _, s in spec:
+        m = 1
+        for d in s:
+            m *= d
+        n += m
+    return n

@@ -1,0 +1,379 @@
+"""ORACLE — TEST INFRASTRUCTURE ONLY.  Never imported by the product path (lightdiffusion-next_amd/).
+
+CPU restatement (plain PyTorch fp32 functional ops) of the reference's denoising hot path for SD1.5, each
+function citing the reference file:line it follows.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this module.
+
+Parity status: the reference (Aatricks/LightDiffusion-Next) has NO tests, golden vectors or KATs
+ — "parity unpinned" by the reference's own suite.  This oracle is therefore pinned
+against outputs of the reference itself, captured in the build container by importing /root/reference
+(oracle/ref_capture.py -> tests/golden/*.npz; checked in tests/test_oracle_vs_golden.py).
+
+Numerics: the reference CPU path stores UNet weights in fp16 and computes in fp32 via cast.manual_cast
+(src/Device/Device.py:980-1012, src/cond/cast.py:44-78, 479-525).  Upcasting the fp16 weights to fp32 once
+and running plain fp32 ops is bit-identical to that path (probed); this file does the latter.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------------
+# schedule / model sampling  (src/sample/sampling.py:221-356, src/sample/sampling_util.py:18-39)
+def make_sigmas():
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2   # sampling_util.py:18-39
+    alphas_cumprod = torch.cumprod(1.0 - betas, dim=0)                                        # sampling.py:268-270
+    sigmas = ((1 - alphas_cumprod) / alphas_cumprod) ** 0.5                                   # sampling.py:276
+    return sigmas.float(), sigmas.log().float()                                               # sampling.py:285-289
+
+
+SIGMAS, LOG_SIGMAS = make_sigmas()
+
+
+def timestep(sigma):
+    """ModelSamplingDiscrete.timestep (sampling.py:309-320): nearest log-sigma table index."""
+    log_sigma = sigma.log()
+    dists = log_sigma - LOG_SIGMAS[:, None]
+    return dists.abs().argmin(dim=0).view(sigma.shape)
+
+
+def sigma_of(t):
+    """ModelSamplingDiscrete.sigma (sampling.py:322-339)."""
+    t = torch.clamp(t.float(), min=0, max=(len(SIGMAS) - 1))
+    low_idx, high_idx, w = t.floor().long(), t.ceil().long(), t.frac()
+    log_sigma = (1 - w) * LOG_SIGMAS[low_idx] + w * LOG_SIGMAS[high_idx]
+    return log_sigma.exp()
+
+
+def timestep_embedding(timesteps, dim, max_period=10000):
+    """sampling_util.py:56-76."""
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+# ---------------------------------------------------------------------------------------------------
+class W:
+    """fp32 view of a (possibly fp16) state dict with prefix navigation."""
+
+    def __init__(self, sd, prefix=""):
+        self.sd, self.prefix = sd, prefix
+
+    def __call__(self, name):
+        return self.sd[self.prefix + name].float()
+
+    def has(self, name):
+        return (self.prefix + name) in self.sd
+
+    def sub(self, p):
+        return W(self.sd, self.prefix + p)
+
+
+def group_norm(x, w, name, eps):
+    return F.group_norm(x, 32, w(name + ".weight"), w(name + ".bias"), eps)           # cast.py:241-243
+
+
+def resblock(w, x, emb):
+    """ResBlock1._forward (src/AutoEncoders/ResBlock.py:315-335); GroupNorm eps 1e-5 (ResBlock.py:252,280)."""
+    h = F.silu(group_norm(x, w, "in_layers.0", 1e-5))
+    h = F.conv2d(h, w("in_layers.2.weight"), w("in_layers.2.bias"), padding=1)
+    emb_out = F.linear(F.silu(emb), w("emb_layers.1.weight"), w("emb_layers.1.bias"))
+    h = h + emb_out[..., None, None]
+    h = F.silu(group_norm(h, w, "out_layers.0", 1e-5))
+    h = F.conv2d(h, w("out_layers.3.weight"), w("out_layers.3.bias"), padding=1)
+    if w.has("skip_connection.weight"):
+        x = F.conv2d(x, w("skip_connection.weight"), w("skip_connection.bias"))
+    return x + h
+
+
+def attention(q, k, v, heads):
+    """attention_pytorch (src/Attention/AttentionMethods.py:107-150): [B,N,H*D] -> SDPA -> [B,N,H*D]."""
+    b, _, inner = q.shape
+    d = inner // heads
+    q, k, v = (t.view(b, -1, heads, d).transpose(1, 2) for t in (q, k, v))
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+    return out.transpose(1, 2).reshape(b, -1, heads * d)
+
+
+def cross_attention(w, x, context, heads):
+    """CrossAttention.forward (src/Attention/Attention.py:100-124): q/k/v without bias, out-proj with bias."""
+    context = x if context is None else context
+    q = F.linear(x, w("to_q.weight"))
+    k = F.linear(context, w("to_k.weight"))
+    v = F.linear(context, w("to_v.weight"))
+    out = attention(q, k, v, heads)
+    return F.linear(out, w("to_out.0.weight"), w("to_out.0.bias"))
+
+
+def basic_transformer_block(w, x, context, heads):
+    """BasicTransformerBlock._forward (src/NeuralNetwork/transformer.py:186-245); LayerNorm eps 1e-5;
+    FeedForward with GEGLU, erf-GELU (transformer.py:19-70, src/cond/Activation.py:6-31)."""
+    c = x.shape[-1]
+    n = F.layer_norm(x, (c,), w("norm1.weight"), w("norm1.bias"))
+    x = x + cross_attention(w.sub("attn1."), n, None, heads)
+    n = F.layer_norm(x, (c,), w("norm2.weight"), w("norm2.bias"))
+    x = x + cross_attention(w.sub("attn2."), n, context, heads)
+    n = F.layer_norm(x, (c,), w("norm3.weight"), w("norm3.bias"))
+    a, gate = F.linear(n, w("ff.net.0.proj.weight"), w("ff.net.0.proj.bias")).chunk(2, dim=-1)
+    ff = F.linear(a * F.gelu(gate), w("ff.net.2.weight"), w("ff.net.2.bias"))
+    return ff + x
+
+
+def spatial_transformer(w, x, context, heads, depth):
+    """SpatialTransformer.forward (transformer.py:342-377), use_linear=False; GroupNorm eps 1e-6 (:286-293)."""
+    b, c, h, wd = x.shape
+    x_in = x
+    x = group_norm(x, w, "norm", 1e-6)
+    x = F.conv2d(x, w("proj_in.weight"), w("proj_in.bias"))
+    x = x.permute(0, 2, 3, 1).reshape(b, h * wd, c)
+    for d in range(depth):
+        x = basic_transformer_block(w.sub(f"transformer_blocks.{d}."), x, context, heads)
+    x = x.reshape(b, h, wd, c).permute(0, 3, 1, 2)
+    x = F.conv2d(x, w("proj_out.weight"), w("proj_out.bias"))
+    return x + x_in
+
+
+def unet_forward(sd, cfg, x, timesteps, context):
+    """UNetModel1.forward (src/NeuralNetwork/unet.py:679-770) for the SD1.5 family; structure walk as in
+    UNetModel1.__init__ (unet.py:344-677).  x fp32 NCHW, timesteps [B] (integer-valued), context [B,M,ctx]."""
+    w = W(sd)
+    mc, heads = cfg.model_channels, cfg.num_heads
+    t_emb = timestep_embedding(timesteps, mc)
+    emb = F.linear(F.silu(F.linear(t_emb, w("time_embed.0.weight"), w("time_embed.0.bias"))),
+                   w("time_embed.2.weight"), w("time_embed.2.bias"))
+    td, tdo = list(cfg.transformer_depth), list(cfg.transformer_depth_output)
+    nl = len(cfg.channel_mult)
+    hs = []
+    h = F.conv2d(x, w("input_blocks.0.0.weight"), w("input_blocks.0.0.bias"), padding=1)
+    hs.append(h)
+    ib = 1
+    for level in range(nl):
+        for _ in range(cfg.num_res_blocks[level]):
+            h = resblock(w.sub(f"input_blocks.{ib}.0."), h, emb)
+            depth = td.pop(0)
+            if depth > 0:
+                h = spatial_transformer(w.sub(f"input_blocks.{ib}.1."), h, context, heads, depth)
+            hs.append(h)
+            ib += 1
+        if level != nl - 1:
+            h = F.conv2d(h, w(f"input_blocks.{ib}.0.op.weight"), w(f"input_blocks.{ib}.0.op.bias"), stride=2, padding=1)
+            hs.append(h)                                                                  # Downsample1 ResBlock.py:141-194
+            ib += 1
+    h = resblock(w.sub("middle_block.0."), h, emb)
+    if cfg.transformer_depth_middle >= 0:
+        h = spatial_transformer(w.sub("middle_block.1."), h, context, heads, cfg.transformer_depth_middle)
+        h = resblock(w.sub("middle_block.2."), h, emb)
+    ob = 0
+    for level in reversed(range(nl)):
+        for i in range(cfg.num_res_blocks[level] + 1):
+            h = torch.cat([h, hs.pop()], dim=1)                                           # unet.py:750
+            output_shape = hs[-1].shape if hs else None                                   # unet.py:754
+            h = resblock(w.sub(f"output_blocks.{ob}.0."), h, emb)
+            sub = 1
+            depth = tdo.pop()
+            if depth > 0:
+                h = spatial_transformer(w.sub(f"output_blocks.{ob}.1."), h, context, heads, depth)
+                sub += 1
+            if level and i == cfg.num_res_blocks[level]:                                  # Upsample1 ResBlock.py:75-138
+                shape = [h.shape[2] * 2, h.shape[3] * 2]
+                if output_shape is not None:
+                    shape = [output_shape[2], output_shape[3]]
+                h = F.interpolate(h, size=shape, mode="nearest")
+                h = F.conv2d(h, w(f"output_blocks.{ob}.{sub}.conv.weight"), w(f"output_blocks.{ob}.{sub}.conv.bias"), padding=1)
+            ob += 1
+    h = F.silu(group_norm(h, w, "out.0", 1e-5))                                           # unet.py:663-677
+    return F.conv2d(h, w("out.2.weight"), w("out.2.bias"), padding=1)
+
+
+def apply_model(sd, cfg, x, sigma, context):
+    """BaseModel.apply_model (src/Model/ModelBase.py:72-133) with EPS (sampling.py:26-56):
+    xc = x / sqrt(sigma^2 + 1); t = timestep(sigma).float(); denoised = x - out * sigma."""
+    s = sigma.view(sigma.shape[:1] + (1,) * (x.ndim - 1))
+    xc = x / (s ** 2 + 1.0) ** 0.5
+    t = timestep(sigma).float()
+    out = unet_forward(sd, cfg, xc.float(), t, context.float()).float()
+    return x - out * s
+
+
+# ---------------------------------------------------------------------------------------------------
+# scheduler loop  (src/sample/*, src/cond/cond.py)
+def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
+    """sampling_util.py:106-125."""
+    ramp = torch.linspace(0, 1, n)
+    min_inv_rho, max_inv_rho = sigma_min ** (1 / rho), sigma_max ** (1 / rho)
+    sigmas = (max_inv_rho + ramp * (min_inv_rho - max_inv_rho)) ** rho
+    return torch.cat([sigmas, sigmas.new_zeros([1])])
+
+
+def calculate_sigmas(scheduler_name, steps):
+    """ksampler_util.py:152-271."""
+    if scheduler_name == "karras":
+        return get_sigmas_karras(steps, float(SIGMAS[0]), float(SIGMAS[-1]))
+    if scheduler_name == "normal":
+        start, end = timestep(SIGMAS[-1]), timestep(SIGMAS[0])
+        ts = torch.linspace(start, end, steps)
+        return torch.FloatTensor([sigma_of(ts[i]) for i in range(len(ts))] + [0.0])
+    if scheduler_name == "simple":
+        ss = len(SIGMAS) / steps
+        return torch.FloatTensor([float(SIGMAS[-(1 + int(x * ss))]) for x in range(steps)] + [0.0])
+    if scheduler_name == "beta":
+        import numpy as np
+        import scipy.stats
+        total = len(SIGMAS) - 1
+        ts = 1 - np.linspace(0, 1, steps, endpoint=False)
+        idx = np.rint(scipy.stats.beta.ppf(ts, 0.6, 0.6) * total).astype(np.int32)
+        uniq, first = np.unique(idx, return_index=True)
+        ordered = uniq[np.argsort(first)]
+        return torch.FloatTensor([float(SIGMAS[i]) for i in ordered] + [0.0])
+    raise ValueError(scheduler_name)
+
+
+def sigmas_for(scheduler, steps, denoise):
+    """sampling.py:966-985 / KSampler.set_steps :665-676."""
+    if denoise is None or denoise > 0.9999:
+        return calculate_sigmas(scheduler, steps)
+    new_steps = int(steps / denoise)
+    return calculate_sigmas(scheduler, new_steps)[-(steps + 1):]
+
+
+def lcm_pad(conds):
+    """CONDCrossAttn.concat (cond.py:100-126)."""
+    lens = [c.shape[1] for c in conds]
+    if all(l == lens[0] for l in lens):
+        return conds
+    target = lens[0]
+    for l in lens[1:]:
+        target = target * l // math.gcd(target, l)
+    return [c.repeat(1, target // c.shape[1], 1) if c.shape[1] < target else c for c in conds]
+
+
+def cfg_denoise(denoiser, x, sigma, positive, negative, cfg, disable_cfg1_optimization=False):
+    """sampling_function + calc_cond_batch + cfg_function (CFG.py:6-161, cond.py:150-288): one batched call
+    in [uncond; cond] order; torch.lerp for the combine."""
+    b = x.shape[0]
+    pos = positive.expand(b, -1, -1) if positive.shape[0] == 1 else positive
+    if math.isclose(cfg, 1.0) and not disable_cfg1_optimization:
+        return denoiser(x, sigma * x.new_ones([b]), pos)
+    neg = negative.expand(b, -1, -1) if negative.shape[0] == 1 else negative
+    neg, pos = lcm_pad([neg, pos])
+    out = denoiser(torch.cat([x, x]), sigma * x.new_ones([2 * b]), torch.cat([neg, pos]))
+    uncond, cond = out.chunk(2)
+    if math.isclose(cfg, 1.0):
+        return cond
+    return torch.lerp(uncond, cond, cfg)
+
+
+class Multiscale:
+    """samplers.py:190-263."""
+
+    def __init__(self, shape, n_steps, enable, factor, start, end, intermittent):
+        self.oh, self.ow = shape[-2:]
+        if enable and not (0.1 <= factor <= 1.0):
+            enable = False
+        if enable and (start < 0 or end < 0):
+            enable = False
+        self.sh = int(max(8, ((self.oh * factor) // 8) * 8)) if enable else self.oh
+        self.sw = int(max(8, ((self.ow * factor) // 8) * 8)) if enable else self.ow
+        self.active = enable and (self.sh != self.oh or self.sw != self.ow)
+        self.n, self.start, self.end, self.intermittent = n_steps, start, end, intermittent
+
+    def fullres(self, i):
+        if not self.active:
+            return True
+        if i < self.start or i >= self.n - self.end:
+            return True
+        if self.intermittent and self.start <= i < self.n - self.end:
+            return (i - self.start) % 2 == 0
+        return False
+
+    def down(self, t):
+        return F.interpolate(t, size=(self.sh, self.sw), mode="bilinear", align_corners=False)
+
+    def up(self, t):
+        return F.interpolate(t, size=(self.oh, self.ow), mode="bilinear", align_corners=False)
+
+
+def sample_euler(model, x, sigmas, enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3,
+                 multiscale_fullres_end=8, multiscale_intermittent_fullres=False, trace=None):
+    """samplers.sample_euler (samplers.py:166-327), s_churn = 0.  model(x, sigma) -> CFG-combined denoised."""
+    n = len(sigmas) - 1
+    ms = Multiscale(x.shape, n, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                    multiscale_fullres_end, multiscale_intermittent_fullres)
+    for i in range(n):
+        sigma_hat = sigmas[i]
+        full = ms.fullres(i)
+        xp = x if full else ms.down(x)
+        if trace is not None:
+            trace.append(tuple(xp.shape[-2:]))
+        denoised = model(xp, sigma_hat)
+        if not full:
+            denoised = ms.up(denoised)
+        x = x + ((x - denoised) / sigma_hat) * (sigmas[i + 1] - sigma_hat)                # util.to_d util.py:26-37
+    return x
+
+
+def sample_dpmpp_2m_cfgpp(model, x, sigmas, enable_multiscale=True, multiscale_factor=0.5,
+                          multiscale_fullres_start=5, multiscale_fullres_end=8,
+                          multiscale_intermittent_fullres=True, trace=None):
+    """samplers.sample_dpmpp_2m_cfgpp (samplers.py:754-962).  old_uncond_denoised is reset to None by the manual
+    post-CFG hook call (samplers.py:910-912) so the first-order branch always runs."""
+    n = len(sigmas) - 1
+    ms = Multiscale(x.shape, n, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                    multiscale_fullres_end, multiscale_intermittent_fullres)
+    t_steps = -torch.log(sigmas)
+    sigma_steps = torch.exp(-t_steps)
+    ratios = sigma_steps[1:] / sigma_steps[:-1]
+    h_steps = t_steps[1:] - t_steps[:-1]
+    for i in range(n):
+        full = ms.fullres(i)
+        xp = x if full else ms.down(x)
+        if trace is not None:
+            trace.append(tuple(xp.shape[-2:]))
+        denoised = model(xp, sigmas[i])
+        if not full:
+            denoised = ms.up(denoised)
+        x = ratios[i] * x - torch.expm1(-h_steps[i]) * denoised
+    return x
+
+
+MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
+
+
+def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent_image, denoise=1.0,
+                    enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3,
+                    multiscale_fullres_end=8, multiscale_intermittent_fullres=False, trace=None):
+    """KSampler.sample -> common_ksampler -> sample1 -> CFGGuider.sample -> KSAMPLER.sample
+    (sampling.py:773-1233, CFG.py:236-357).  denoiser(x[2B], sigma[2B], ctx[2B]) is apply_model."""
+    denoise = denoise or 1.0                                                              # sampling.py:875
+    latent_image = latent_image.float()
+    generator = torch.manual_seed(seed)                                                   # ksampler_util.py:287-295
+    noise = torch.randn(latent_image.size(), dtype=latent_image.dtype, layout=latent_image.layout,
+                        generator=generator, device="cpu")
+    sigmas = sigmas_for(scheduler, steps, denoise)
+    if sampler_name == "dpmpp_2m_cfgpp":                                                  # sampling.py:517-532
+        fn, disable_cfg1 = sample_dpmpp_2m_cfgpp, True
+    elif sampler_name in ("euler_ancestral_cfgpp", "dpmpp_sde_cfgpp", "euler_cfgpp"):
+        raise NotImplementedError(sampler_name)
+    else:
+        fn, disable_cfg1 = sample_euler, False
+    extra = {}
+    if sampler_name in MULTISCALE_WHITELIST:                                              # sampling.py:949-964
+        extra = dict(enable_multiscale=enable_multiscale, multiscale_factor=multiscale_factor,
+                     multiscale_fullres_start=multiscale_fullres_start, multiscale_fullres_end=multiscale_fullres_end,
+                     multiscale_intermittent_fullres=multiscale_intermittent_fullres)
+    if torch.count_nonzero(latent_image) > 0:                                             # CFG.py:266-269
+        latent_image = latent_image * 0.18215
+    max_sigma, s0 = float(SIGMAS[-1]), float(sigmas[0])                                   # sampling.py:410-422
+    if math.isclose(max_sigma, s0, rel_tol=1e-05) or s0 > max_sigma:
+        x = noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)                                    # sampling.py:58-83
+    else:
+        x = noise * sigmas[0]
+    x = x + latent_image
+
+    def model(xx, sigma):
+        return cfg_denoise(denoiser, xx, sigma, positive, negative, cfg, disable_cfg1)
+
+    x = fn(model, x, sigmas, trace=trace, **extra)
+    return x / 0.18215                                                                    # CFG.py:294
