@@ -1,4 +1,5 @@
 // extern "C" surface of libldx.so (include/ldx.h).  No exceptions cross the ABI.
+#include <cstring>
 #include <new>
 
 #include "engine.h"
@@ -80,6 +81,19 @@ int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* ar
     if (n_launches) *n_launches = e->impl->n_launches();
     if (flops) *flops = e->impl->flops;
     if (arena_bytes) *arena_bytes = (int64_t)e->impl->arena_cap;
+    return LDX_OK;
+}
+int ldx_profile(ldx_engine* e, int enable, int reset) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    e->impl->profiling = enable != 0;
+    if (reset) e->impl->prof.clear();
+    return LDX_OK;
+}
+int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap) {
+    if (!e || !buf || cap <= 0) { set_error("ldx_profile_report: bad argument"); return LDX_EINVAL; }
+    const std::string s = e->impl->profile_json();
+    if ((int64_t)s.size() + 1 > cap) { set_error("ldx_profile_report: buffer too small"); return LDX_EINVAL; }
+    memcpy(buf, s.c_str(), s.size() + 1);
     return LDX_OK;
 }
 int ldx_set_graph_mode(ldx_engine* e, int enable) {

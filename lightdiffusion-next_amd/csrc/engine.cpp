@@ -436,8 +436,11 @@ void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bo
     g.geglu = geglu ? 1 : 0;
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = ptr(C); g.ldc = C.ld; g.Cf = nullptr;
+    o.flops = 2.0 * g.M * (double)g.N * g.K;
+    o.bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * (geglu ? g.N / 2 : g.N) * (R.valid ? 2 : 1));
+    snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
     ops.push_back(o);
-    flops += 2.0 * g.M * (double)g.N * g.K;
+    flops += o.flops;
 }
 void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, const LinearW& w, int stride, int Hout, int Wout,
                      Act Y, Act R, const float* rowvec, int rv_ld, float* Cf, int ldcf) {
@@ -450,20 +453,27 @@ void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, 
     g.bias = w.b; g.rowvec = rowvec; g.rowvec_ld = rv_ld; g.rows_per_batch = Hout * Wout;
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = Y.valid ? ptr(Y) : nullptr; g.ldc = Y.ld; g.Cf = Cf; g.ldcf = ldcf;
+    o.flops = 2.0 * g.M * (double)g.N * g.K;
+    o.bytes = 2.0 * ((double)B * Hin * Win * Cin + (double)g.N * g.K + (double)g.M * g.N * (R.valid ? 2 : 1));
+    snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,1>", dt == DT_BF16 ? "bf16" : "f16");
     ops.push_back(o);
-    flops += 2.0 * g.M * (double)g.N * g.K;
+    flops += o.flops;
 }
 void Engine::op_gn(const char* name, Act X, Act Y, int B, int HW, const NormW& n, float eps, bool silu) {
     Op o{}; o.kind = OP_GN; o.name = name;
     GroupNormArgs& g = o.gn;
     g.X = ptr(X); g.ldx = X.ld; g.Y = ptr(Y); g.ldy = Y.ld; g.B = B; g.HW = HW; g.C = n.C; g.G = 32; g.eps = eps; g.silu = silu;
     g.gamma = n.g; g.beta = n.b; g.partial = (float*)(arena ? (char*)arena + gn_ws_off : nullptr);
+    o.bytes = 2.0 * 3.0 * (double)B * HW * n.C;       // read (stats) + read + write (apply)
+    snprintf(o.klabel, sizeof(o.klabel), "gn_stats+gn_apply");
     ops.push_back(o);
 }
 void Engine::op_ln(const char* name, Act X, Act Y, const NormW& n) {
     Op o{}; o.kind = OP_LN; o.name = name;
     LayerNormArgs& l = o.ln;
     l.X = ptr(X); l.ldx = X.ld; l.Y = ptr(Y); l.ldy = Y.ld; l.rows = X.rows; l.C = n.C; l.eps = 1e-5f; l.gamma = n.g; l.beta = n.b;
+    o.bytes = 2.0 * 2.0 * (double)X.rows * n.C;
+    snprintf(o.klabel, sizeof(o.klabel), "ln_kernel");
     ops.push_back(o);
 }
 void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, Act O, int B, int H, int Nq, int Mk, int D) {
@@ -471,8 +481,15 @@ void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, in
     AttnArgs& a = o.at;
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ptr(O); a.ldo = O.ld;
     a.B = B; a.H = H; a.Nq = Nq; a.Mk = Mk; a.D = D; a.scale = 1.0f / std::sqrt((float)D); a.causal = 0;
+    o.flops = 4.0 * B * H * (double)Nq * Mk * D;
+    o.bytes = 2.0 * (double)B * H * D * (2.0 * Nq + 2.0 * Mk);
+    {
+        const int ks = D <= 32 ? 1 : D <= 64 ? 2 : D <= 96 ? 3 : D <= 128 ? 4 : 5;
+        const int dtl = D <= 16 ? 1 : D <= 32 ? 2 : D <= 48 ? 3 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6 : D <= 128 ? 8 : 10;
+        snprintf(o.klabel, sizeof(o.klabel), "attn_kernel<%s,%d,%d>%s", dt == DT_BF16 ? "bf16" : "f16", ks, dtl, Nq == Mk ? "self" : "cross");
+    }
     ops.push_back(o);
-    flops += 4.0 * B * H * (double)Nq * Mk * D;
+    flops += o.flops;
 }
 
 Act Engine::new_act(int rows, int C) {
@@ -716,7 +733,15 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         ls = cap_stream;
     }
+    const bool prof_now = profiling && !use_graph;
+    if (prof_now && prof_events.size() < 2 * ops.size()) {
+        const size_t old = prof_events.size();
+        prof_events.resize(2 * ops.size());
+        for (size_t i = old; i < prof_events.size(); ++i) HIP_OK(hipEventCreate(&prof_events[i]));
+    }
+    size_t oi = 0;
     for (const Op& o : ops) {
+        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi], ls));
         switch (o.kind) {
             case OP_PREP: {
                 PrepArgs p{};
@@ -739,6 +764,19 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
                 launch_finish(f, ls);
             } break;
         }
+        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
+        ++oi;
+    }
+    if (prof_now) {
+        HIP_OK(hipStreamSynchronize(ls));
+        for (size_t i = 0; i < ops.size(); ++i) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
+            const Op& o = ops[i];
+            std::string key = o.klabel[0] ? o.klabel : o.name;
+            ProfEntry& pe = prof[key];
+            pe.count += 1; pe.ms += ms; pe.flops += o.flops; pe.bytes += o.bytes;
+        }
     }
     if (use_graph) {
         hipGraph_t g = nullptr;
@@ -751,6 +789,18 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
     return LDX_OK;
+}
+
+std::string Engine::profile_json() const {
+    std::string s = "{";
+    bool first = true;
+    char buf[256];
+    for (auto& kv : prof) {
+        snprintf(buf, sizeof(buf), "%s\"%s\": {\"count\": %ld, \"ms\": %.6f, \"flops\": %.6e, \"bytes\": %.6e}", first ? "" : ", ",
+                 kv.first.c_str(), kv.second.count, kv.second.ms, kv.second.flops, kv.second.bytes);
+        s += buf; first = false;
+    }
+    return s + "}";
 }
 
 int64_t Engine::n_launches() const {

@@ -39,7 +39,9 @@ struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk;
     void* cvt_out; size_t cvt_n;
+    double flops; double bytes; char klabel[48];
 };
+struct ProfEntry { long count = 0; double ms = 0, flops = 0, bytes = 0; };
 
 struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
@@ -54,6 +56,10 @@ public:
     int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st);
     int plan(int B2, int h, int w, int Mc);
     int64_t n_launches() const;
+    // per-kernel-class HIP-event profile of subsequent forwards (bench.py roofline leg)
+    bool profiling = false;
+    std::map<std::string, ProfEntry> prof;
+    std::string profile_json() const;
 
     ldx_unet_config cfg;
     int device;
@@ -112,6 +118,7 @@ private:
     void emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W);
     void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc);
 
+    std::vector<hipEvent_t> prof_events;
     // graph replay
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;

@@ -107,6 +107,15 @@ class UNetEngine:
         """UNetModel1.forward (unet.py:679-770): integer timesteps (as floats), unscaled input."""
         return self._run(self._lib.ldx_unet_forward, x, timesteps, ctx, out)
 
+    def profile(self, on: bool, reset: bool = True):
+        lib.check(self._lib.ldx_profile(self._h, int(on), int(reset)), "ldx_profile")
+
+    def profile_report(self) -> dict:
+        import json
+        buf = C.create_string_buffer(1 << 16)
+        lib.check(self._lib.ldx_profile_report(self._h, buf, len(buf)), "ldx_profile_report")
+        return json.loads(buf.value.decode())
+
     def plan_info(self):
         n, f, a = C.c_int64(), C.c_double(), C.c_int64()
         lib.check(self._lib.ldx_plan_info(self._h, C.byref(n), C.byref(f), C.byref(a)), "ldx_plan_info")

@@ -45,6 +45,8 @@ _SIGS = {
     "ldx_unet_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_plan_info": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
+    "ldx_profile": (_i, [_vp, _i, _i]),
+    "ldx_profile_report": (_i, [_vp, C.c_char_p, _i64]),
     "ldx_set_graph_mode": (_i, [_vp, _i]),
     "ldx_sampler_step": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
     "ldx_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),

@@ -1,0 +1,154 @@
+"""The drop-in path on a real MI355X vs the oracle and the committed reference goldens.
+
+Everything goes through libldx.so's C ABI (ldx_unet_denoise & co).  Tolerances (stated):
+  fp16-activation engine mode (separates kernel bugs from precision): one UNet forward rel-L2 <= 4e-3
+  bf16 engine (the benchmarked mode):  one forward rel-L2 <= 2.5e-2, cosine >= 0.9995;
+                                       20-step latents rel-L2 <= 5e-2, cosine >= 0.999
+These are the reference's own bf16-vs-fp32 CPU spreads (1.9e-2..2.9e-2), not looser.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sd15_oracle as O  # noqa: E402  (checker only)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def _cos(a, b):
+    a, b = a.double().cpu().flatten(), torch.as_tensor(b).double().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+@pytest.fixture(scope="module")
+def setup(ldx, ldx_lib, golden_dir):
+    cfg = ldx.UNetConfig.tiny(64, 128)
+    sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234)
+    g = np.load(os.path.join(golden_dir, "unet_mc64.npz"))
+    eng = {dt: ldx.UNetEngine(cfg, sd, device=0, dtype=dt) for dt in ("bf16", "f16")}
+    return cfg, sd, g, eng
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_unet_forward_vs_reference_golden(setup, dt, tol):
+    cfg, sd, g, eng = setup
+    y = eng[dt].forward(torch.from_numpy(g["unet_x"]).cuda(), torch.from_numpy(g["unet_t"]).cuda(), torch.from_numpy(g["unet_ctx"]).cuda())
+    r, c = _rel(y, g["unet_y"]), _cos(y, g["unet_y"])
+    print(f"[{dt}] UNet forward vs reference golden: rel-L2 {r:.3e} cos {c:.6f}")
+    assert r <= tol and c >= 0.9995
+    yo = eng[dt].forward(torch.from_numpy(g["odd_x"]).cuda(), torch.tensor([500.0]).cuda(), torch.from_numpy(g["unet_ctx"][:1]).cuda())
+    r = _rel(yo, g["odd_y"])
+    print(f"[{dt}] odd-size forward: rel-L2 {r:.3e}")
+    assert r <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_denoise_vs_reference_golden(setup, dt, tol):
+    cfg, sd, g, eng = setup
+    d = eng[dt].denoise(torch.from_numpy(g["unet_x"]).cuda(), torch.from_numpy(g["am_sigma"]).cuda(), torch.from_numpy(g["unet_ctx"]).cuda())
+    r = _rel(d, g["am_out"])
+    print(f"[{dt}] apply_model vs reference golden: rel-L2 {r:.3e}")
+    assert r <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_wrapper_hook_contract(setup, ldx, dt, tol):
+    """Feed the recorded hook inputs (cond.py:254-263) to LdxUNetPatch exactly as the reference would."""
+    cfg, sd, g, eng = setup
+    patch = ldx.LdxUNetPatch(eng[dt])
+    import copy
+    assert copy.deepcopy(patch) is patch and patch.to("cuda") is patch
+    for i in range(int(g["hook_n"])):
+        params = {"input": torch.from_numpy(g[f"hook{i}_input"]), "timestep": torch.from_numpy(g[f"hook{i}_timestep"]),
+                  "c": {"c_crossattn": torch.from_numpy(g[f"hook{i}_ctx"]), "transformer_options": {}},
+                  "cond_or_uncond": list(g[f"hook{i}_cou"])}
+        out = patch(None, params)
+        assert out.device.type == "cpu" and out.dtype == torch.float32 and len(out.chunk(2)) == 2
+        r = _rel(out, g[f"hook{i}_out"])
+        print(f"[{dt}] hook call {i}: rel-L2 {r:.3e}")
+        assert r <= tol
+
+
+def test_timestep_lookup_on_device(setup):
+    """sigma -> table index is integer work: the device argmin must agree with the reference exactly."""
+    cfg, sd, g, eng = setup
+    sched = np.load(os.path.join(os.path.dirname(__file__), "golden", "schedules.npz"))
+    # the engine exposes t only through the embedding; compare denoise at sigma with forward at the golden index
+    sig = torch.from_numpy(sched["timestep_in"][:24:3].copy())
+    tt = torch.from_numpy(sched["timestep_out"][:24:3].copy()).float()
+    e = eng["f16"]
+    gen = torch.Generator().manual_seed(2)
+    x = torch.randn([len(sig), 4, 8, 8], generator=gen)
+    ctx = torch.randn([len(sig), 77, 128], generator=gen)
+    d = e.denoise(x.cuda(), sig.cuda(), ctx.cuda()).cpu()
+    s = sig.view(-1, 1, 1, 1)
+    y = e.forward((x / (s ** 2 + 1) ** 0.5).cuda(), tt.cuda(), ctx.cuda()).cpu()
+    assert torch.allclose(d, x - y * s, rtol=1e-4, atol=1e-4)
+
+
+RUNS = {
+    "euler_ms_off": dict(sampler_name="sample_euler", scheduler="normal", enable_multiscale=False),
+    "euler_ms_on": dict(sampler_name="sample_euler", scheduler="normal", enable_multiscale=True),
+    "euler_forced": dict(sampler_name="euler", scheduler="karras", enable_multiscale=False),
+    "dpmpp2m": dict(sampler_name="dpmpp_2m_cfgpp", scheduler="karras", enable_multiscale=False),
+}
+
+
+@pytest.mark.parametrize("name", list(RUNS))
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_ksampler_end_to_end(setup, ldx, name, dt, tol):
+    cfg, sd, g, eng = setup
+    ks = ldx.sampling.KSampler(eng[dt])
+    trace = []
+    out = ks.sample(seed=42, steps=20, cfg=7.0, positive=torch.from_numpy(g["P"]), negative=torch.from_numpy(g["N"]),
+                    latent_image=torch.zeros(1, 4, 16, 16), trace=trace, **RUNS[name])
+    assert [t[-1] for t in trace] == list(g[f"ks_{name}_res"])
+    r, c = _rel(out, g[f"ks_{name}"]), _cos(out, g[f"ks_{name}"])
+    print(f"[{dt}] KSampler {name}: rel-L2 {r:.3e} cos {c:.6f}")
+    assert r <= tol and c >= 0.999
+
+
+def test_img2img_and_batch(setup, ldx):
+    cfg, sd, g, eng = setup
+    ks = ldx.sampling.KSampler(eng["f16"])
+    out = ks.sample(seed=3, steps=10, cfg=5.0, denoise=0.45, positive=torch.from_numpy(g["P"]), negative=torch.from_numpy(g["N"]),
+                    latent_image=torch.from_numpy(g["ks_img2img_latent"]), sampler_name="sample_euler", scheduler="normal", enable_multiscale=False)
+    assert _rel(out, g["ks_img2img"]) <= 1e-2
+    # batch of 3, 2 steps: equals the reference's recorded final latents (hook_final)
+    out = ks.sample(seed=11, steps=2, cfg=7.0, positive=torch.from_numpy(g["P"]), negative=torch.from_numpy(g["N"]),
+                    latent_image=torch.zeros(3, 4, 8, 8), sampler_name="sample_euler", scheduler="karras", enable_multiscale=False)
+    assert _rel(out, g["hook_final"]) <= 1e-2
+
+
+def test_graph_replay_matches_eager(setup):
+    cfg, sd, g, eng = setup
+    e = eng["bf16"]
+    x = torch.from_numpy(g["unet_x"]).cuda(); s = torch.from_numpy(g["am_sigma"]).cuda(); c = torch.from_numpy(g["unet_ctx"]).cuda()
+    out = torch.empty_like(x)
+    ref = e.denoise(x, s, c).clone()
+    e.set_graph_mode(True)
+    for _ in range(4):
+        e.denoise(x, s, c, out=out)
+    torch.cuda.synchronize()
+    e.set_graph_mode(False)
+    assert torch.equal(out, ref)            # same kernels, same order: bit-identical
+
+
+def test_determinism_and_errors(setup, ldx):
+    cfg, sd, g, eng = setup
+    e = eng["bf16"]
+    x = torch.from_numpy(g["unet_x"]).cuda(); s = torch.from_numpy(g["am_sigma"]).cuda(); c = torch.from_numpy(g["unet_ctx"]).cuda()
+    a, b = e.denoise(x, s, c).clone(), e.denoise(x, s, c).clone()
+    assert torch.equal(a, b)
+    bad = dict(sd); bad.pop("out.2.weight")
+    with pytest.raises(ldx.lib.LdxError):
+        ldx.UNetEngine(cfg, bad, device=0)
+    with pytest.raises(ldx.lib.LdxError):
+        ldx.UNetEngine(ldx.UNetConfig.tiny(32, 64), sd, device=0)       # model_channels % 64 != 0
