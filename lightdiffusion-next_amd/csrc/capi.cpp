@@ -27,6 +27,25 @@ static int check_launch(const char* what) {
     return LDX_OK;
 }
 
+// scratch for the single-op entry points (split-K partials); grown on demand, never shrunk
+static float* op_workspace(size_t floats) {
+    static float* buf = nullptr; static size_t cap = 0;
+    if (floats > cap) {
+        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
+        if (hipMalloc((void**)&buf, floats * 4) != hipSuccess) return nullptr;
+        cap = floats;
+    }
+    return buf;
+}
+static int attach_splitk(GemmArgs& g) {
+    g.splitk = gemm_choose_splitk(g.M, g.N, g.K, g.geglu != 0);
+    if (g.splitk > 1) {
+        g.ws = op_workspace((size_t)g.splitk * g.M * g.N);
+        if (!g.ws) { set_error("split-K workspace allocation failed"); return LDX_EHIP; }
+    }
+    return LDX_OK;
+}
+
 extern "C" {
 
 const char* ldx_version(void) { return "ldx 0.1 (gfx950)"; }
@@ -127,6 +146,7 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.mode = 0; g.bias = bias;
     g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.geglu = geglu;
     g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cf = Cf; g.ldcf = ldcf;
+    if (int rc = attach_splitk(g)) return rc;
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm");
 }
@@ -141,6 +161,7 @@ int ldx_op_conv3x3(const void* X, int ldx_, const void* W, int B, int Hin, int W
     g.resize = (g.Hv != Hin || g.Wv != Win) ? 1 : 0;
     g.bias = bias; g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = Hout * Wout;
     g.R = R; g.ldr = ldr; g.C = Y; g.ldc = ldy;
+    if (int rc = attach_splitk(g)) return rc;
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_conv3x3");
 }

@@ -436,6 +436,8 @@ void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bo
     g.geglu = geglu ? 1 : 0;
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = ptr(C); g.ldc = C.ld; g.Cf = nullptr;
+    g.splitk = gemm_choose_splitk(g.M, g.N, g.K, geglu);
+    if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * (geglu ? g.N / 2 : g.N) * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
@@ -453,6 +455,8 @@ void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, 
     g.bias = w.b; g.rowvec = rowvec; g.rowvec_ld = rv_ld; g.rows_per_batch = Hout * Wout;
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = Y.valid ? ptr(Y) : nullptr; g.ldc = Y.ld; g.Cf = Cf; g.ldcf = ldcf;
+    g.splitk = gemm_choose_splitk(g.M, g.N, g.K, false);
+    if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)B * Hin * Win * Cin + (double)g.N * g.K + (double)g.M * g.N * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,1>", dt == DT_BF16 ? "bf16" : "f16");
@@ -805,7 +809,7 @@ std::string Engine::profile_json() const {
 
 int64_t Engine::n_launches() const {
     int64_t n = 0;
-    for (const Op& o : ops) n += (o.kind == OP_GN || o.kind == OP_PREP) ? 2 : 1;
+    for (const Op& o : ops) n += (o.kind == OP_GN || o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1)) ? 2 : 1;
     return n;
 }
 

@@ -33,10 +33,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     const int tiles_n = (p.N + BN - 1) / BN;
     const int tiles_m = (p.M + BM - 1) / BM;
-    const int bid = xcd_remap(blockIdx.x, tiles_m * tiles_n);
+    const int ntiles = tiles_m * tiles_n;
+    const int S = p.splitk > 1 ? p.splitk : 1;
+    const int lin = xcd_remap(blockIdx.x, ntiles * S);
+    const int bid = lin % ntiles, split = lin / ntiles;      // same-split tiles adjacent: neighbours share panels
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk = p.K / BK;
+    const int nk_all = p.K / BK;
+    const int kt_begin = (int)((long)split * nk_all / S), kt_end = (int)((long)(split + 1) * nk_all / S);
+    const int nk = kt_end - kt_begin;
 
     // ---- per-thread staging coordinates: 4 A chunks + 4 W chunks of 16 B per K-tile ----
     const int srow = tid >> 3;        // 0..31 (+32*j)
@@ -76,8 +81,12 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
     uint4 ra[4], rb[4];
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
+    if (MODE == 1 && kt_begin > 0) {
+        const int k0 = kt_begin * BK, tap = k0 / p.Cin;
+        st_ci = k0 - tap * p.Cin; st_ky = tap / 3; st_kx = tap - st_ky * 3;
+    }
     auto gload = [&](int kt) {
-        const int k0 = kt * BK;
+        const int k0 = (kt_begin + kt) * BK;
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < 4; ++j)
@@ -154,6 +163,22 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         __syncthreads();
     }
 
+    // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
+    if (S > 1) {
+        float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int m = m0 + wm * 64 + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int n = n0 + wn * 64 + j * 16 + 4 * g4;
+                if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
     const T* __restrict__ Rp = (const T*)p.R;
     T* __restrict__ Cp = (T*)p.C;
@@ -211,9 +236,46 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     }
 }
 
+// sum the split-K partials (fixed order -> deterministic) and apply the epilogue; one thread per 4 columns
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
+    const int nq = (p.N + 3) / 4;
+    const long total = (long)p.M * nq;
+    const T* __restrict__ Rp = (const T*)p.R;
+    T* __restrict__ Cp = (T*)p.C;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        const bool full = n + 3 < p.N;
+        for (int sidx = 0; sidx < p.splitk; ++sidx) {
+            const float* w = p.ws + ((size_t)sidx * p.M + m) * p.N + n;
+            if (full) { const float4 t = *(const float4*)w; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+            else for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += w[r];
+        }
+        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        for (int r = 0; r < 4 && n + r < p.N; ++r) {
+            float x = v[r];
+            if (p.bias) x += p.bias[n + r];
+            if (rv) x += rv[n + r];
+            if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+            v[r] = x;
+        }
+        if (full) {
+            if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(v[r]);
+                if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = v[r];
+            }
+        }
+    }
+}
+
 template <typename T>
 static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN);
+    const int S = (a.splitk > 1 && a.ws && !a.geglu) ? a.splitk : 1;
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * STAGE_BYTES;
     if (a.mode == 0) {
         static bool attr0 = false;
@@ -224,6 +286,23 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
         hipLaunchKernelGGL((gemm_kernel<T, 1>), dim3(tiles), dim3(256), lds, s, a);
     }
+    if (S > 1) {
+        long total = (long)a.M * ((a.N + 3) / 4);
+        int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
+        hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, s, a);
+    }
+}
+
+// heuristic shared with the planner: how many K splits for an (M, N, K) problem
+int gemm_choose_splitk(int M, int N, int K, bool geglu) {
+    if (geglu) return 1;
+    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int nk = K / BK;
+    if (tiles >= 200 || nk < 12) return 1;
+    int s = 560 / tiles;
+    if (s > nk / 5) s = nk / 5;
+    if (s > 16) s = 16;
+    return s < 2 ? 1 : s;
 }
 
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {

@@ -36,8 +36,11 @@ struct GemmArgs {
     const void* R; int ldr;        // residual (16-bit) or null
     void* C; int ldc;              // 16-bit output or null
     float* Cf; int ldcf;           // fp32 output or null
+    int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
+                                   // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
 };
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
+int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
 
 // Skinny GEMM for tiny M (time embedding path): out[m][n] = bias[n] + sum_k act(x[m][k]) W[n][k]
 // x, out fp32; W 16-bit [N][K]; act: 0 none, 1 SiLU on the input (reference ResBlock emb_layers:

@@ -41,7 +41,8 @@ def _st():
 
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
-@pytest.mark.parametrize("M,N,K,lda_extra", [(300, 200, 128, 0), (1024, 320, 320, 64), (154, 640, 768, 0), (32768, 320, 320, 0), (513, 4, 2880 // 64 * 64, 0)])
+@pytest.mark.parametrize("M,N,K,lda_extra", [(300, 200, 128, 0), (1024, 320, 320, 64), (154, 640, 768, 0), (32768, 320, 320, 0), (513, 4, 2880 // 64 * 64, 0),
+                                              (2048, 1280, 1280, 0), (512, 1280, 2560, 0)])   # last three take the split-K path
 def test_gemm(L, ldx, dt, M, N, K, lda_extra):
     td, code = DT[dt]
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
@@ -94,6 +95,8 @@ CONV_CASES = [
     (1, 5, 7, 64, 64, 1, 9, 13, 1, 0),          # resize to an odd skip shape
     (2, 64, 64, 320, 320, 1, 64, 64, 0, 0),
     (1, 16, 16, 64, 4, 1, 16, 16, 0, 0),        # Cout = 4 (UNet out conv)
+    (2, 16, 16, 1280, 1280, 1, 16, 16, 0, 0),   # split-K path (40 tiles, 180 K-tiles)
+    (2, 33, 31, 640, 640, 2, 17, 16, 0, 0),     # split-K + stride 2
 ]
 
 
