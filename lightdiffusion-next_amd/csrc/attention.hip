@@ -10,8 +10,14 @@
 // With the 16x16x32 MFMA result layout (col = lane&15, rows = 4*(lane>>4)+r) the query index of
 // every accumulator in both S^T and O^T is lane&15, so running max / rescale / denominator need
 // no cross-lane traffic except one 4-lane max per 64-key block.  The k-slot <-> key permutation
-// induced by feeding S^T accumulators straight back as the P operand is absorbed by reading the
-// V^T fragment as two 8-byte pieces (keys 4g..4g+3 of two 16-key tiles).
+// induced by feeding S^T accumulators straight back as the P operand is absorbed by the V operand:
+// V stays row-major [key][d] in LDS (plain 16-byte staging writes) and each V^T fragment is two
+// ds_read_b64_tr_b16 hardware-transposing reads (4 keys x 16 d per 16-lane group: keys 4g..4g+3 of
+// two 16-key tiles).  Cross-lane max / sum use v_permlane16/32_swap (VALU), not LDS bpermute.
+//
+// The softmax denominator is not summed on the VALU: V carries a constant column of ones at d = D (the
+// PV tile is padded to 16*DT > D anyway), so the same MFMA that accumulates O^T also accumulates
+// l[q] = sum_k P[q][k] in row D of O^T, rescaled with O for free.
 //
 // Workgroup = 4 waves x 32 queries; K and V^T tiles of 64 keys double-buffered in LDS, global
 // loads register-staged one block ahead.  Head dims D in {8..160}, D % 8 == 0: the QK^T
@@ -24,25 +30,57 @@ namespace ldx {
 constexpr int AT_KV = 64;         // keys per block
 constexpr int AT_QW = 32;         // queries per wave
 constexpr int AT_QB = 128;        // queries per workgroup
-constexpr int VT_ROWB = AT_KV * 2 + 16;   // V^T LDS row bytes (64 keys + 16 B pad)
 
-template <int KS> struct AttnCfg { static constexpr int KROWB = KS * 64 + 16; };  // K LDS row bytes (padded)
+// LDS row strides.  K rows: KS*64 B + 32 B pad -> the four 16-lane groups of ds_read_b128 are conflict-free
+// (brute-forced over the real lane groups).  V rows: >= DT*32 B and == 32 (mod 64) so the 8 key rows a
+// 32-lane half touches in one ds_read_b64_tr_b16 tile the 64 banks.
+template <int KS, int DT> struct AttnCfg {
+    static constexpr int KROWB = KS * 64 + 32;
+    static constexpr int VROWB = (DT * 32) % 64 == 0 ? DT * 32 + 32 : DT * 32;
+};
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+__device__ __forceinline__ uint2 lds_read_tr16(const char* p) {
+    const s16x4 v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+    union { s16x4 v; uint2 u; } x; x.v = v; return x.u;
+}
+// value of lane^16 / lane^32 combined with own value; v_permlane*_swap with both operands = v leaves
+// {own, partner} in the two results (order depends on the lane), so a commutative op needs no select.
+__device__ __forceinline__ float quad_max(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float quad_sum(float v) {
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 
 template <typename T, int KS, int DT>
-__global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
+__global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
-    constexpr int KROWB = AttnCfg<KS>::KROWB;
+    constexpr int KROWB = AttnCfg<KS, DT>::KROWB;
+    constexpr int VROWB = AttnCfg<KS, DT>::VROWB;
     constexpr int KBYTES = AT_KV * KROWB;
-    constexpr int VBYTES = DT * 16 * VT_ROWB;
+    constexpr int VBYTES = AT_KV * VROWB;
     constexpr int STAGE = KBYTES + VBYTES;
     constexpr int MAXCH = (KS * 4 > DT * 2) ? KS * 4 : DT * 2;     // upper bound on D/8
     constexpr int NLD = (AT_KV * MAXCH + 255) / 256;                // staging chunks per thread
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l15 = lane & 15, g4 = lane >> 4;
-    const int h = blockIdx.y, b = blockIdx.z;
-    const int q0 = blockIdx.x * AT_QB + wave * AT_QW;
+    // XCD-aware work order: block b runs on XCD b % 8 with a private 4 MiB L2, so each XCD is given a
+    // contiguous run of (batch, head, q-block) work: its resident workgroups then stream the SAME head's
+    // K/V (a few MB) instead of eight XCDs each thrashing over every head.
+    const int nqb = (p.Nq + AT_QB - 1) / AT_QB;
+    const int lin = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int qblk = lin % nqb, hb = lin / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qblk * AT_QB + wave * AT_QW;
     const int D = p.D, dch = D >> 3;           // 16-B chunks per head row
     const T* __restrict__ Qp = (const T*)p.Q + (long)b * p.Nq * p.ldq + h * D;
     const T* __restrict__ Kp = (const T*)p.K + (long)b * p.Mk * p.ldk + h * D;
@@ -50,8 +88,11 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     T* __restrict__ Op = (T*)p.O + (long)b * p.Nq * p.ldo + h * D;
     const float c = p.scale * 1.44269504088896340736f;
 
-    // zero both LDS stages once: K pad columns (d >= D) and V^T pad rows must read as 0.
+    // zero both LDS stages once: K pad columns (d >= D) and V pad columns must read as 0 ...
     for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    // ... except V column D, which is the constant 1 that makes row D of O^T the softmax denominator.
+    if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROWB + D * 2) = (T)1.0f;
 
     // Q fragments (B operand): lane holds q = l15, d = ks*32 + g4*8 .. +7
     V8 qf[2][KS];
@@ -73,20 +114,21 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     float mrun[2] = {-INFINITY, -INFINITY};
-    float lrun[2] = {0.f, 0.f};
 
     // number of key blocks this workgroup needs (causal: keys <= last query of the block)
     int mk_eff = p.Mk;
-    if (p.causal) mk_eff = min(p.Mk, blockIdx.x * AT_QB + AT_QB);
+    if (p.causal) mk_eff = min(p.Mk, qblk * AT_QB + AT_QB);
     const int nblk = (mk_eff + AT_KV - 1) / AT_KV;
 
     uint4 rk[NLD], rv[NLD];
+    int ld_row[NLD], ld_ch[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) { const int idx = tid + i * 256; ld_row[i] = idx / dch; ld_ch[i] = idx - ld_row[i] * dch; }
     auto gload = [&](int blk) {
         const int kv0 = blk * AT_KV;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / dch, ch = idx - row * dch;
+            const int row = ld_row[i], ch = ld_ch[i];
             const int kv = kv0 + row;
             const bool ok = row < AT_KV && kv < p.Mk;
             rk[i] = ok ? *(const uint4*)(Kp + (long)kv * p.ldk + ch * 8) : make_uint4(0, 0, 0, 0);
@@ -98,20 +140,15 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
         char* sV = sK + KBYTES;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int idx = tid + i * 256;
-            const int row = idx / dch, ch = idx - row * dch;
+            const int row = ld_row[i], ch = ld_ch[i];
             if (row < AT_KV) {
                 *(uint4*)(sK + row * KROWB + ch * 16) = rk[i];
-                // transpose V[kv=row][d = ch*8+e] -> V^T[d][kv]
-                union { uint4 u; unsigned short s[8]; } x; x.u = rv[i];
-#pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    *(unsigned short*)(sV + (ch * 8 + e) * VT_ROWB + row * 2) = x.s[e];
+                *(uint4*)(sV + row * VROWB + ch * 16) = rv[i];      // row-major; transposed on the read side
             }
         }
     };
 
-    __syncthreads();      // zero-fill visible before first tile lands
+    __syncthreads();      // zero / ones fill visible before the first tile lands
     if (nblk > 0) { gload(0); lstore(0); }
     __syncthreads();
 
@@ -140,7 +177,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
         }
 
         // ---- masking (block-uniform fast path) ----
-        const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > blockIdx.x * AT_QB));
+        const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > qblk * AT_QB));
         if (need_mask) {
 #pragma unroll
             for (int qt = 0; qt < 2; ++qt) {
@@ -165,14 +202,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) mx = fmaxf(mx, s[qt][t][r]);
-            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            mx = quad_max(mx);
             const float mnew = fmaxf(mrun[qt], mx);
             // rows with every key masked so far keep mnew = -inf; guard the (-inf) - (-inf) case
             const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;
             const float alpha = __builtin_amdgcn_exp2f(mrun[qt] * c - mc);
             mrun[qt] = mnew;
-            float psum = 0.f;
             float pv[4][4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -180,9 +215,7 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
                 for (int r = 0; r < 4; ++r) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][t][r], c, -mc));
                     pv[t][r] = e;
-                    psum += e;
                 }
-            lrun[qt] = lrun[qt] * alpha + psum;
 #pragma unroll
             for (int dt = 0; dt < DT; ++dt) {
                 o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
@@ -201,10 +234,12 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
-                const char* vrow = sV + (dt * 16 + l15) * VT_ROWB;
+                // 16-lane group g4 fetches keys ks2*32 + 4*g4 + {0..3} (+16 for the second read), d = dt*16 + 0..15:
+                // lane i of the group addresses 4 contiguous d of key (i>>2) and receives column d = dt*16 + i.
+                const char* vp = sV + (ks2 * 32 + g4 * 4 + (l15 >> 2)) * VROWB + (dt * 16 + (l15 & 3) * 4) * 2;
                 U128 vf;
-                vf.d[0] = *(const uint2*)(vrow + (ks2 * 32 + g4 * 4) * 2);
-                vf.d[1] = *(const uint2*)(vrow + (ks2 * 32 + 16 + g4 * 4) * 2);
+                vf.d[0] = lds_read_tr16(vp);
+                vf.d[1] = lds_read_tr16(vp + 16 * VROWB);
                 const V8 v8 = as_v8<T>(vf.u);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma16(v8, pf[qt][ks2], o[qt][dt]);
@@ -218,9 +253,8 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
     // ---- finalize: O = O^T / l ; lane holds q = l15, d = dt*16 + 4*g4 + r ----
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
-        float l = lrun[qt];
-        l += __shfl_xor(l, 16, 64);
-        l += __shfl_xor(l, 32, 64);
+        // denominator = O^T row D: tile DT-1, lanes with g4 == (D % 16) / 4, register 0
+        const float l = quad_sum(g4 == ((D & 15) >> 2) ? o[qt][DT - 1][0] : 0.f);
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;
         const int q = q0 + qt * 16 + l15;
         if (q >= p.Nq) continue;
@@ -236,25 +270,31 @@ __global__ __launch_bounds__(256) void attn_kernel(const AttnArgs p) {
 
 template <typename T, int KS, int DT>
 static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
-    constexpr int STAGE = AT_KV * AttnCfg<KS>::KROWB + DT * 16 * VT_ROWB;
+    constexpr int STAGE = AT_KV * (AttnCfg<KS, DT>::KROWB + AttnCfg<KS, DT>::VROWB);
     const size_t lds = 2 * STAGE;
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn_kernel<T, KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    dim3 grid((a.Nq + AT_QB - 1) / AT_QB, a.H, a.B);
+    dim3 grid(((a.Nq + AT_QB - 1) / AT_QB) * a.H * a.B);
     hipLaunchKernelGGL((attn_kernel<T, KS, DT>), grid, dim3(256), lds, s, a);
 }
 
 template <typename T>
 static void launch_attn_d(const AttnArgs& a, hipStream_t s) {
     const int D = a.D;
-    if (D <= 16) launch_attn_t<T, 1, 1>(a, s);
-    else if (D <= 32) launch_attn_t<T, 1, 2>(a, s);
-    else if (D <= 48) launch_attn_t<T, 2, 3>(a, s);
-    else if (D <= 64) launch_attn_t<T, 2, 4>(a, s);
-    else if (D <= 80) launch_attn_t<T, 3, 5>(a, s);
-    else if (D <= 96) launch_attn_t<T, 3, 6>(a, s);
-    else if (D <= 128) launch_attn_t<T, 4, 8>(a, s);
-    else launch_attn_t<T, 5, 10>(a, s);
+    // KS = ceil(D/32) contraction steps, DT = floor(D/16) + 1 output tiles (room for the ones column at d = D)
+    if (D < 16) launch_attn_t<T, 1, 1>(a, s);
+    else if (D < 32) launch_attn_t<T, 1, 2>(a, s);
+    else if (D == 32) launch_attn_t<T, 1, 3>(a, s);
+    else if (D < 48) launch_attn_t<T, 2, 3>(a, s);
+    else if (D < 64) launch_attn_t<T, 2, 4>(a, s);
+    else if (D == 64) launch_attn_t<T, 2, 5>(a, s);
+    else if (D < 80) launch_attn_t<T, 3, 5>(a, s);
+    else if (D < 96) launch_attn_t<T, 3, 6>(a, s);
+    else if (D == 96) launch_attn_t<T, 3, 7>(a, s);
+    else if (D < 128) launch_attn_t<T, 4, 8>(a, s);
+    else if (D == 128) launch_attn_t<T, 4, 9>(a, s);
+    else if (D < 160) launch_attn_t<T, 5, 10>(a, s);
+    else launch_attn_t<T, 5, 11>(a, s);
 }
 
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {

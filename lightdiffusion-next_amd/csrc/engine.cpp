@@ -489,7 +489,7 @@ void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, in
     o.bytes = 2.0 * (double)B * H * D * (2.0 * Nq + 2.0 * Mk);
     {
         const int ks = D <= 32 ? 1 : D <= 64 ? 2 : D <= 96 ? 3 : D <= 128 ? 4 : 5;
-        const int dtl = D <= 16 ? 1 : D <= 32 ? 2 : D <= 48 ? 3 : D <= 64 ? 4 : D <= 80 ? 5 : D <= 96 ? 6 : D <= 128 ? 8 : 10;
+        const int dtl = D / 16 + 1;
         snprintf(o.klabel, sizeof(o.klabel), "attn_kernel<%s,%d,%d>%s", dt == DT_BF16 ? "bf16" : "f16", ks, dtl, Nq == Mk ? "self" : "cross");
     }
     ops.push_back(o);

@@ -1,0 +1,82 @@
+"""Micro-probe: time single ops through the C ABI (HIP events on torch's current stream, which is the launch
+stream).  Usage: python profiles/kprobe.py attn|gemm|conv|gn [reps]"""
+import ctypes as C
+import math
+import sys
+
+import torch
+
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ldx_amd as ldx
+
+L = ldx.lib.load()
+p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
+st = lambda: C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def timeit(fn, reps=20, warm=3):
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+def attn(B=2, H=8, N=16384, M=None, D=40, reps=10):
+    M = M or N
+    C_ = H * D
+    qkv = torch.randn(B, N, 3 * C_, device="cuda").bfloat16()
+    O = torch.empty(B, N, C_, device="cuda", dtype=torch.bfloat16)
+    fn = lambda: L.ldx_op_attention(p(qkv), 3 * C_, p(qkv[..., C_:]), 3 * C_, p(qkv[..., 2 * C_:]), 3 * C_, p(O), C_, B, H, N, M, D, 1 / math.sqrt(D), 0, 0, st())
+    ms = timeit(fn, reps)
+    fl = 4.0 * B * H * N * M * D
+    print(f"attn B{B} H{H} N{N} M{M} D{D}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
+
+
+def gemm(M=32768, N=320, K=320, reps=20):
+    A = torch.randn(M, K, device="cuda").bfloat16()
+    W = torch.randn(N, K, device="cuda").bfloat16()
+    Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    fn = lambda: L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, 0, None, 0, p(Cc), N, None, 0, 0, st())
+    ms = timeit(fn, reps)
+    print(f"gemm {M}x{N}x{K}: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+
+
+def conv(B=2, H=128, Cin=320, Cout=320, reps=10):
+    X = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+    W = torch.randn(Cout, 9 * Cin, device="cuda").bfloat16()
+    Y = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.bfloat16)
+    fn = lambda: L.ldx_op_conv3x3(p(X), Cin, p(W), B, H, H, Cin, Cout, 1, H, H, 0, None, None, 0, None, 0, p(Y), Cout, 0, st())
+    ms = timeit(fn, reps)
+    print(f"conv B{B} {H}x{H} {Cin}->{Cout}: {ms * 1000:.1f} us  {2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9:.1f} TFLOP/s")
+
+
+def gn(B=2, HW=16384, Cn=320, reps=20):
+    X = torch.randn(B, HW, Cn, device="cuda").bfloat16()
+    Y = torch.empty_like(X)
+    g = torch.ones(Cn, device="cuda"); b = torch.zeros(Cn, device="cuda")
+    ws = torch.zeros(L.ldx_op_groupnorm_workspace_floats(B, 32), device="cuda")
+    fn = lambda: L.ldx_op_groupnorm(p(X), Cn, p(Y), Cn, B, HW, Cn, 32, 1e-5, 1, p(g), p(b), p(ws), 0, st())
+    ms = timeit(fn, reps)
+    print(f"gn B{B} HW{HW} C{Cn}: {ms * 1000:.1f} us  {3 * 2.0 * B * HW * Cn / ms / 1e6:.1f} GB/s (3 passes)")
+
+
+if __name__ == "__main__":
+    what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "attn1":
+        attn(reps=3)
+    if what in ("attn", "all"):
+        attn(); attn(N=4096, D=80); attn(N=1024, D=160); attn(N=16384, M=77)
+    if what in ("gemm", "all"):
+        for s in ((32768, 320, 320), (32768, 960, 320), (32768, 2560, 320), (32768, 320, 1280), (8192, 640, 640), (8192, 5120, 640), (8192, 640, 2560),
+                  (2048, 1280, 1280), (2048, 10240, 1280), (2048, 1280, 5120), (8192, 8192, 8192)):
+            gemm(*s)
+    if what in ("conv", "all"):
+        conv(); conv(H=64, Cin=640, Cout=640); conv(H=32, Cin=1280, Cout=1280); conv(H=16, Cin=1280, Cout=1280); conv(H=16, Cin=2560, Cout=1280)
+    if what in ("gn", "all"):
+        gn(); gn(HW=4096, Cn=640); gn(HW=1024, Cn=1280); gn(HW=256, Cn=2560)
