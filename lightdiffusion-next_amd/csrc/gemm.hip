@@ -18,11 +18,16 @@
 
 namespace ldx {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int STAGE_BYTES = (BM + BN) * BK * 2;   // 32 KiB
+constexpr int BM = 128, BK = 64;
+// BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
+// 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)
+// that N = 320 / 960 / 1920 get with 128.
+template <int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
 
-template <typename T, int MODE>
+template <typename T, int MODE, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+    constexpr int NJ = BN / 32;                 // 16-column MFMA tiles per wave (wave = 64 x BN/2)
+    constexpr int STAGE_BYTES = stage_bytes<BN>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
 
@@ -31,7 +36,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int l15 = lane & 15, g4 = lane >> 4;
 
-    const int tiles_n = (p.N + BN - 1) / BN;
+    const int tiles_n = (p.N + BN - 1) / BN;   // BN = template tile width
     const int tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int S = p.splitk > 1 ? p.splitk : 1;
@@ -68,10 +73,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             a_ox[j] = ox * p.stride - 1;
         }
     }
-    long w_off[4];
-    bool w_ok[4];
+    long w_off[NJ];
+    bool w_ok[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < NJ; ++j) {
         const int n = n0 + srow + 32 * j;
         w_ok[j] = n < p.N;
         w_off[j] = (long)n * p.K + schunk * 8;
@@ -79,7 +84,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
     const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
 
-    uint4 ra[4], rb[4];
+    uint4 ra[4], rb[NJ];
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
     if (MODE == 1 && kt_begin > 0) {
         const int k0 = kt_begin * BK, tap = k0 / p.Cin;
@@ -108,26 +113,26 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             }
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NJ; ++j)
             rb[j] = w_ok[j] ? *(const uint4*)(Wp + w_off[j] + k0) : make_uint4(0, 0, 0, 0);
     };
     auto lstore = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;
         char* sB = sA + BM * BK * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             const int row = srow + 32 * j;
             const int off = row * 128 + ((schunk ^ (row & 7)) << 4);
-            *(uint4*)(sA + off) = ra[j];
+            if (j < 4) *(uint4*)(sA + off) = ra[j < 4 ? j : 0];
             *(uint4*)(sB + off) = rb[j];
         }
     };
 
-    f32x4 acc[4][4];
+    f32x4 acc[4][NJ];
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     gload(0);
     lstore(0);
@@ -141,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            V8 af[4], bf[4];
+            V8 af[4], bf[NJ];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int row = wm * 64 + i * 16 + l15;
@@ -149,15 +154,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 af[i] = as_v8<T>(*(const uint4*)(sA + row * 128 + (ch << 4)));
             }
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int row = wn * 64 + j * 16 + l15;
+            for (int j = 0; j < NJ; ++j) {
+                const int row = wn * (BN / 2) + j * 16 + l15;
                 const int ch = (ks * 4 + g4) ^ (row & 7);
                 bf[j] = as_v8<T>(*(const uint4*)(sB + row * 128 + (ch << 4)));
             }
 #pragma unroll
             for (int i = 0; i < 4; ++i)
 #pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
         }
         if (more) lstore(cur ^ 1);
         __syncthreads();
@@ -171,8 +176,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const int m = m0 + wm * 64 + i * 16 + l15;
             if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + 4 * g4;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
                 if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
                 else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
             }
@@ -187,10 +192,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int m = m0 + wm * 64 + i * 16 + l15;
         if (m >= p.M) continue;
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
-        if (!p.geglu) {
+        if (BN != 128 || !p.geglu) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int n = n0 + wn * 64 + j * 16 + 4 * g4;
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
                 if (n >= p.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const bool full = (n + 3) < p.N;
@@ -211,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     }
                 }
             }
-        } else {
+        } else if (BN == 128) {
             // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -220,7 +225,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (ng >= p.N) continue;
                 const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                float g[4] = {acc[i][j + 2][0], acc[i][j + 2][1], acc[i][j + 2][2], acc[i][j + 2][3]};
+                constexpr int JG = (BN == 128) ? 2 : 0;
+                float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
                 if (p.bias) {
                     const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
                     a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
@@ -272,20 +278,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+static inline int gemm_bn(const GemmArgs& a) { return (!a.geglu && a.N % 160 == 0 && a.N % 128 != 0) ? 160 : 128; }
+
+template <typename T, int MODE, int BN>
+static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
+    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
+    const size_t lds = 2 * stage_bytes<BN>();
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, BN>), dim3(tiles), dim3(256), lds, s, a);
+}
+
 template <typename T>
 static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int S = (a.splitk > 1 && a.ws && !a.geglu) ? a.splitk : 1;
-    const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
-    const size_t lds = 2 * STAGE_BYTES;
-    if (a.mode == 0) {
-        static bool attr0 = false;
-        if (!attr0) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr0 = true; }
-        hipLaunchKernelGGL((gemm_kernel<T, 0>), dim3(tiles), dim3(256), lds, s, a);
-    } else {
-        static bool attr1 = false;
-        if (!attr1) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr1 = true; }
-        hipLaunchKernelGGL((gemm_kernel<T, 1>), dim3(tiles), dim3(256), lds, s, a);
-    }
+    const bool wide = gemm_bn(a) == 160;
+    if (a.mode == 0) { if (wide) launch_gemm_inst<T, 0, 160>(a, S, s); else launch_gemm_inst<T, 0, 128>(a, S, s); }
+    else             { if (wide) launch_gemm_inst<T, 1, 160>(a, S, s); else launch_gemm_inst<T, 1, 128>(a, S, s); }
     if (S > 1) {
         long total = (long)a.M * ((a.N + 3) / 4);
         int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
@@ -296,7 +305,8 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 // heuristic shared with the planner: how many K splits for an (M, N, K) problem
 int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     if (geglu) return 1;
-    const int tiles = ((M + BM - 1) / BM) * ((N + BN - 1) / BN);
+    const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+    const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int nk = K / BK;
     if (tiles >= 200 || nk < 12) return 1;
     int s = 560 / tiles;

@@ -69,8 +69,9 @@ struct GroupNormArgs {
     int B, HW, C, G; float eps; int silu;
     const float* gamma; const float* beta;
     float* partial;                // workspace [B][GN_NCHUNK][G][2]
+    int nchunk;                    // pixel chunks actually used (<= GN_NCHUNK), set by the launcher
 };
-constexpr int GN_NCHUNK = 32;
+constexpr int GN_NCHUNK = 256;
 void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s);
 
 // LayerNorm over the last dim C of [rows][ldx] -> [rows][ldy]

@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs p, in
     const int tid = threadIdx.x;
     const int tx = tid % TX, ty = tid / TX;
     const int b = blockIdx.y, chunk = blockIdx.x;
-    const int per = (p.HW + GN_NCHUNK - 1) / GN_NCHUNK;
+    const int per = (p.HW + p.nchunk - 1) / p.nchunk;
     const int pb = chunk * per, pe = min(p.HW, pb + per);
     const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx;
 
@@ -68,22 +68,32 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs p, in
         float acc = 0.f;
         for (int r = 0; r < RY; ++r)
             for (int c = g * cpg; c < (g + 1) * cpg; ++c) acc += sred[(r * p.C + c) * 2 + st];
-        p.partial[(((long)b * GN_NCHUNK + chunk) * p.G + g) * 2 + st] = acc;
+        p.partial[(((long)b * p.nchunk + chunk) * p.G + g) * 2 + st] = acc;
     }
 }
 
 template <typename T, int CH>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, int TX, int RY, int nblk) {
     __shared__ float smean[64], srstd[64];
+    __shared__ float sred[8][32][2];
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int cpg = p.C / p.G;
+    {   // fold the per-chunk partials: 8 slices x 32 groups, fixed order (deterministic)
+        const int g = tid & 31, sl = tid >> 5;
+        float su = 0.f, sq = 0.f;
+        if (g < p.G)
+            for (int ck = sl; ck < p.nchunk; ck += 8) {
+                const float* pp = p.partial + (((long)b * p.nchunk + ck) * p.G + g) * 2;
+                su += pp[0]; sq += pp[1];
+            }
+        sred[sl][g][0] = su; sred[sl][g][1] = sq;
+    }
+    __syncthreads();
     if (tid < p.G) {
         float su = 0.f, sq = 0.f;
-        for (int ck = 0; ck < GN_NCHUNK; ++ck) {
-            const float* pp = p.partial + (((long)b * GN_NCHUNK + ck) * p.G + tid) * 2;
-            su += pp[0]; sq += pp[1];
-        }
+#pragma unroll
+        for (int sl = 0; sl < 8; ++sl) { su += sred[sl][tid][0]; sq += sred[sl][tid][1]; }
         const float n = (float)p.HW * (float)cpg;
         const float mean = su / n;
         const float var = fmaxf(sq / n - mean * mean, 0.f);
@@ -125,9 +135,17 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, in
 }
 
 template <typename T>
-static void launch_gn_t(const GroupNormArgs& a, hipStream_t s) {
+static void launch_gn_t(const GroupNormArgs& a_in, hipStream_t s) {
+    GroupNormArgs a = a_in;
     const GnGeom g = gn_geom(a.C);
-    dim3 grid1(GN_NCHUNK, a.B);
+    // enough pixel chunks to fill the chip (~1024 workgroups), but >= 4 pixels per thread row
+    int nchunk = (1024 + a.B - 1) / a.B;
+    const int maxc = (a.HW + g.RY * 4 - 1) / (g.RY * 4);
+    if (nchunk > maxc) nchunk = maxc;
+    if (nchunk > GN_NCHUNK) nchunk = GN_NCHUNK;
+    if (nchunk < 1) nchunk = 1;
+    a.nchunk = nchunk;
+    dim3 grid1(nchunk, a.B);
     const size_t lds = (size_t)g.RY * a.C * 2 * sizeof(float);
     int nblk = (a.HW + g.RY * 8 - 1) / (g.RY * 8);
     if (nblk > 512) nblk = 512;
