@@ -48,73 +48,92 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int kt_begin = (int)((long)split * nk_all / S), kt_end = (int)((long)(split + 1) * nk_all / S);
     const int nk = kt_end - kt_begin;
 
-    // ---- per-thread staging coordinates: 4 A chunks + 4 W chunks of 16 B per K-tile ----
+    // ---- per-thread staging coordinates: 4 A chunks + NJ W chunks of 16 B per K-tile ----
+    // Loads go through buffer descriptors (buffer_load_dwordx4 ... offen with an SGPR K offset): the per-lane
+    // byte offsets are loop-invariant (plain GEMM) or change only when the 3x3 tap changes (conv), and rows
+    // outside M / N / the zero-padding halo use an out-of-range offset, which the hardware returns as 0 —
+    // no exec-mask branches, no 64-bit address arithmetic in the K loop.
     const int srow = tid >> 3;        // 0..31 (+32*j)
     const int schunk = tid & 7;       // 16-B chunk within the 128-B K-slice
+    constexpr int OOB = (int)0x80000000;
     const T* __restrict__ Ap = (const T*)p.A;
     const T* __restrict__ Wp = (const T*)p.W;
+    const int hw = (MODE == 1) ? p.Hout * p.Wout : 1;
+    const int b0 = (MODE == 1) ? m0 / hw : 0;
+    const long img = (long)p.Hin * p.Win * p.lda;                       // conv: elements per input image
+    const long a_base = (MODE == 0) ? (long)m0 * p.lda : (long)b0 * img;
+    const long a_total = (MODE == 0) ? (long)(p.M - 1) * p.lda + p.K : ((long)(p.M / hw) * p.Hin * p.Win - 1) * p.lda + p.Cin;
+    const long a_rem = (a_total - a_base) * 2;
+    const long w_rem = ((long)p.N * p.K - (long)n0 * p.K) * 2;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ap + a_base), 0, (int)(a_rem > 0x7fffffffL ? 0x7fffffffL : a_rem), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.K), 0, (int)(w_rem > 0x7fffffffL ? 0x7fffffffL : w_rem), 0x00020000);
 
-    long a_off[4];      // plain: row offset ; conv: batch base offset
+    int a_voff[4];                    // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
+    int a_pix[4];                     // conv: byte offset of this row's batch image + chunk
     int a_oy[4], a_ox[4];
-    bool a_ok[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int m = m0 + srow + 32 * j;
-        a_ok[j] = m < p.M;
+        const bool ok = m < p.M;
         if (MODE == 0) {
-            a_off[j] = (long)m * p.lda + schunk * 8;
-            a_oy[j] = a_ox[j] = 0;
+            a_voff[j] = ok ? ((srow + 32 * j) * p.lda + schunk * 8) * 2 : OOB;
+            a_pix[j] = a_oy[j] = a_ox[j] = 0;
         } else {
-            const int hw = p.Hout * p.Wout;
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
-            a_off[j] = (long)b * p.Hin * p.Win * p.lda + schunk * 8;
+            a_pix[j] = ok ? (int)(((long)(b - b0) * img + schunk * 8) * 2) : OOB;
             a_oy[j] = oy * p.stride - 1;
             a_ox[j] = ox * p.stride - 1;
+            a_voff[j] = OOB;
         }
     }
-    long w_off[NJ];
-    bool w_ok[NJ];
+    int w_voff[NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
         const int n = n0 + srow + 32 * j;
-        w_ok[j] = n < p.N;
-        w_off[j] = (long)n * p.K + schunk * 8;
+        w_voff[j] = n < p.N ? ((srow + 32 * j) * p.K + schunk * 8) * 2 : OOB;
     }
     const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
     const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
 
     uint4 ra[4], rb[NJ];
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
+    bool st_new_tap = true;
     if (MODE == 1 && kt_begin > 0) {
         const int k0 = kt_begin * BK, tap = k0 / p.Cin;
         st_ci = k0 - tap * p.Cin; st_ky = tap / 3; st_kx = tap - st_ky * 3;
     }
+    auto ld128 = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
+        const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
+        return make_uint4(v[0], v[1], v[2], v[3]);
+    };
     auto gload = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                ra[j] = a_ok[j] ? *(const uint4*)(Ap + a_off[j] + k0) : make_uint4(0, 0, 0, 0);
+            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, a_voff[j], k0 * 2);
         } else {
-            const int ky = st_ky, kx = st_kx, ci0 = st_ci;   // running (tap, channel) state, no divides
-            st_ci += BK;
-            if (st_ci >= p.Cin) { st_ci = 0; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
+            if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                int iy = a_oy[j] + ky, ix = a_ox[j] + kx;
-                const bool ok = a_ok[j] && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
-                if (p.resize) {   // nearest: src = min(floor(dst * in/out), in-1)  (torch upsample_nearest)
-                    iy = min((int)floorf((float)iy * rs_y), p.Hin - 1);
-                    ix = min((int)floorf((float)ix * rs_x), p.Win - 1);
+                for (int j = 0; j < 4; ++j) {
+                    int iy = a_oy[j] + st_ky, ix = a_ox[j] + st_kx;
+                    const bool ok = a_pix[j] != OOB && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
+                    if (p.resize) {   // nearest: src = min(floor(dst * in/out), in-1)  (torch upsample_nearest)
+                        iy = min((int)floorf((float)iy * rs_y), p.Hin - 1);
+                        ix = min((int)floorf((float)ix * rs_x), p.Win - 1);
+                    }
+                    a_voff[j] = ok ? a_pix[j] + (iy * p.Win + ix) * p.lda * 2 : OOB;
                 }
-                const long off = a_off[j] + ((long)iy * p.Win + ix) * p.lda + ci0;
-                ra[j] = ok ? *(const uint4*)(Ap + off) : make_uint4(0, 0, 0, 0);
             }
+            const int soff = st_ci * 2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, a_voff[j], soff);
+            st_ci += BK;
+            st_new_tap = false;
+            if (st_ci >= p.Cin) { st_ci = 0; st_new_tap = true; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j)
-            rb[j] = w_ok[j] ? *(const uint4*)(Wp + w_off[j] + k0) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < NJ; ++j) rb[j] = ld128(rW, w_voff[j], k0 * 2);
     };
     auto lstore = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;

@@ -68,6 +68,10 @@ def gn(B=2, HW=16384, Cn=320, reps=20):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "all"
+    if what == "conv1":
+        conv(reps=3)
+    if what == "gemm1":
+        gemm(8192, 8192, 8192, reps=2)
     if what == "attn1":
         attn(reps=3)
     if what in ("attn", "all"):
