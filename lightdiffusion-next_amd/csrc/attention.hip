@@ -28,8 +28,8 @@
 namespace ldx {
 
 constexpr int AT_KV = 64;         // keys per block
-constexpr int AT_QW = 32;         // queries per wave
-constexpr int AT_QB = 128;        // queries per workgroup
+// queries per wave = 16 * QT, per workgroup = 64 * QT (QT = 2, or 4 for small head dims where the
+// accumulators fit: K/V staging and fragment reads are then amortised over twice the queries)
 
 // LDS row strides.  K rows: KS*64 B + 32 B pad -> the four 16-lane groups of ds_read_b128 are conflict-free
 // (brute-forced over the real lane groups).  V rows: >= DT*32 B and == 32 (mod 64) so the 8 key rows a
@@ -59,8 +59,9 @@ __device__ __forceinline__ float quad_sum(float v) {
     return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
 
-template <typename T, int KS, int DT>
+template <typename T, int KS, int DT, int QT>
 __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
+    constexpr int AT_QW = 16 * QT, AT_QB = 64 * QT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
     constexpr int KROWB = AttnCfg<KS, DT>::KROWB;
@@ -95,9 +96,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROWB + D * 2) = (T)1.0f;
 
     // Q fragments (B operand): lane holds q = l15, d = ks*32 + g4*8 .. +7
-    V8 qf[2][KS];
+    V8 qf[QT][KS];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         const int q = q0 + qt * 16 + l15;
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
@@ -108,42 +109,56 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         }
     }
 
-    f32x4 o[2][DT];
+    f32x4 o[QT][DT];
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt)
+    for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) o[qt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    float mrun[2] = {-INFINITY, -INFINITY};
+    float mrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mrun[qt] = -INFINITY;
 
     // number of key blocks this workgroup needs (causal: keys <= last query of the block)
     int mk_eff = p.Mk;
     if (p.causal) mk_eff = min(p.Mk, qblk * AT_QB + AT_QB);
     const int nblk = (mk_eff + AT_KV - 1) / AT_KV;
 
+    // K/V staging through buffer descriptors: per-lane byte offsets advance by one key block per iteration,
+    // keys >= Mk (and staging slots beyond the 64 x D/8 tile) fall outside num_records and load as zeros —
+    // no exec-mask branches or 64-bit address math in the loop.
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
     uint4 rk[NLD], rv[NLD];
-    int ld_row[NLD], ld_ch[NLD];
+    int ko[NLD], vo[NLD], lk[NLD], lv[NLD];
 #pragma unroll
-    for (int i = 0; i < NLD; ++i) { const int idx = tid + i * 256; ld_row[i] = idx / dch; ld_ch[i] = idx - ld_row[i] * dch; }
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / dch, ch = idx - row * dch;
+        const bool in_tile = row < AT_KV;
+        ko[i] = in_tile ? (row * p.ldk + ch * 8) * 2 : OOB;
+        vo[i] = in_tile ? (row * p.ldv + ch * 8) * 2 : OOB;
+        lk[i] = in_tile ? row * KROWB + ch * 16 : -1;
+        lv[i] = in_tile ? KBYTES + row * VROWB + ch * 16 : -1;
+    }
+    const int kstep = AT_KV * p.ldk * 2, vstep = AT_KV * p.ldv * 2;
     auto gload = [&](int blk) {
-        const int kv0 = blk * AT_KV;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int row = ld_row[i], ch = ld_ch[i];
-            const int kv = kv0 + row;
-            const bool ok = row < AT_KV && kv < p.Mk;
-            rk[i] = ok ? *(const uint4*)(Kp + (long)kv * p.ldk + ch * 8) : make_uint4(0, 0, 0, 0);
-            rv[i] = ok ? *(const uint4*)(Vp + (long)kv * p.ldv + ch * 8) : make_uint4(0, 0, 0, 0);
+            const bool live = ko[i] != OOB;
+            const auto a = __builtin_amdgcn_raw_buffer_load_b128(rK, live ? ko[i] + blk * kstep : OOB, 0, 0);
+            const auto c2 = __builtin_amdgcn_raw_buffer_load_b128(rV, live ? vo[i] + blk * vstep : OOB, 0, 0);
+            rk[i] = make_uint4(a[0], a[1], a[2], a[3]);
+            rv[i] = make_uint4(c2[0], c2[1], c2[2], c2[3]);
         }
     };
     auto lstore = [&](int stage) {
-        char* sK = smem + stage * STAGE;
-        char* sV = sK + KBYTES;
+        char* sB = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
-            const int row = ld_row[i], ch = ld_ch[i];
-            if (row < AT_KV) {
-                *(uint4*)(sK + row * KROWB + ch * 16) = rk[i];
-                *(uint4*)(sV + row * VROWB + ch * 16) = rv[i];      // row-major; transposed on the read side
+            if (lk[i] >= 0) {
+                *(uint4*)(sB + lk[i]) = rk[i];
+                *(uint4*)(sB + lv[i]) = rv[i];      // V row-major; transposed on the read side
             }
         }
     };
@@ -161,9 +176,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         const int kv0 = blk * AT_KV;
 
         // ---- S^T = K Q^T : 4 key tiles x 2 query tiles ----
-        f32x4 s[2][4];
+        f32x4 s[QT][4];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt)
+        for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -172,7 +187,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
             for (int t = 0; t < 4; ++t) {
                 const V8 kf = as_v8<T>(*(const uint4*)(sK + (t * 16 + l15) * KROWB + (ks * 4 + g4) * 16));
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) s[qt][t] = mfma16(kf, qf[qt][ks], s[qt][t]);
+                for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(kf, qf[qt][ks], s[qt][t]);
             }
         }
 
@@ -180,7 +195,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > qblk * AT_QB));
         if (need_mask) {
 #pragma unroll
-            for (int qt = 0; qt < 2; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const int q = q0 + qt * 16 + l15;
 #pragma unroll
                 for (int t = 0; t < 4; ++t)
@@ -194,9 +209,9 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         }
 
         // ---- online softmax; P packed as B-operand fragments ----
-        V8 pf[2][2];
+        V8 pf[QT][2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
+        for (int qt = 0; qt < QT; ++qt) {
             float mx = s[qt][0][0];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
@@ -242,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
                 vf.d[1] = lds_read_tr16(vp + 16 * VROWB);
                 const V8 v8 = as_v8<T>(vf.u);
 #pragma unroll
-                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma16(v8, pf[qt][ks2], o[qt][dt]);
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(v8, pf[qt][ks2], o[qt][dt]);
             }
         }
 
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 
     // ---- finalize: O = O^T / l ; lane holds q = l15, d = dt*16 + 4*g4 + r ----
 #pragma unroll
-    for (int qt = 0; qt < 2; ++qt) {
+    for (int qt = 0; qt < QT; ++qt) {
         // denominator = O^T row D: tile DT-1, lanes with g4 == (D % 16) / 4, register 0
         const float l = quad_sum(g4 == ((D & 15) >> 2) ? o[qt][DT - 1][0] : 0.f);
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;
@@ -268,14 +283,23 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     }
 }
 
-template <typename T, int KS, int DT>
-static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
+template <typename T, int KS, int DT, int QT>
+static void launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int STAGE = AT_KV * (AttnCfg<KS, DT>::KROWB + AttnCfg<KS, DT>::VROWB);
+    constexpr int QB = 64 * QT;
     const size_t lds = 2 * STAGE;
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_kernel<T, KS, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    dim3 grid(((a.Nq + AT_QB - 1) / AT_QB) * a.H * a.B);
-    hipLaunchKernelGGL((attn_kernel<T, KS, DT>), grid, dim3(256), lds, s, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_kernel<T, KS, DT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
+    hipLaunchKernelGGL((attn_kernel<T, KS, DT, QT>), grid, dim3(256), lds, s, a);
+}
+template <typename T, int KS, int DT>
+static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
+    // 64 queries per wave when the accumulators fit (DT <= 3) and the grid still fills the chip
+    if constexpr (DT <= 3) {
+        if ((long)((a.Nq + 255) / 256) * a.H * a.B >= 512 && !a.causal) { launch_attn_q<T, KS, DT, 4>(a, s); return; }
+    }
+    launch_attn_q<T, KS, DT, 2>(a, s);
 }
 
 template <typename T>
