@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
             for (int t = 0; t < 4; ++t) s[qt][t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
@@ -190,6 +191,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
                 for (int qt = 0; qt < QT; ++qt) s[qt][t] = mfma16(kf, qf[qt][ks], s[qt][t]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 
         // ---- masking (block-uniform fast path) ----
         const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > qblk * AT_QB));
@@ -245,6 +247,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         }
 
         // ---- O^T += V^T P^T ----
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int dt = 0; dt < DT; ++dt) {
 #pragma unroll
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
                 for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma16(v8, pf[qt][ks2], o[qt][dt]);
             }
         }
+        __builtin_amdgcn_s_setprio(0);
 
         if (more) lstore(cur ^ 1);
         __syncthreads();
