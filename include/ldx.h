@@ -50,6 +50,30 @@ typedef struct ldx_unet_config {
     int32_t context_dim;                /* 768; multiple of 64 */
 } ldx_unet_config;
 
+/* VAE decoder (AutoencoderKL) — kwargs of Decoder.__init__ (src/AutoEncoders/VariationalAE.py:416-530) with the
+ * ddconfig VAE.__init__ builds (VariationalAE.py:612-640). */
+typedef struct ldx_vae_config {
+    int32_t compute_dtype;      /* LDX_BF16 | LDX_F16 (the reference decodes in fp32 on CPU/ROCm, VAE_DTYPE) */
+    int32_t z_channels;         /* 4 */
+    int32_t ch;                 /* 128 ; multiple of 64 */
+    int32_t num_levels;         /* 4 */
+    int32_t ch_mult[8];         /* 1,2,4,4 */
+    int32_t num_res_blocks;     /* 2 */
+    int32_t out_ch;             /* 3 */
+    int32_t use_post_quant;     /* 1 for SD1.5 (AutoencodingEngine.decode, VariationalAE.py:130-145); 0 for Flux */
+} ldx_vae_config;
+
+/* CLIP text encoder — keys of include/clip/sd1_clip_config.json read by CLIPTextModel_ (src/clip/CLIPTextModel.py:3-50). */
+typedef struct ldx_clip_config {
+    int32_t compute_dtype;
+    int32_t hidden_size;            /* 768 */
+    int32_t num_layers;             /* 12 */
+    int32_t num_heads;              /* 12 */
+    int32_t intermediate_size;      /* 3072 */
+    int32_t max_positions;          /* 77 */
+    int32_t vocab_size;             /* 49408 */
+} ldx_clip_config;
+
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 const char* ldx_version(void);
 const char* ldx_last_error(void);
@@ -89,6 +113,21 @@ int ldx_profile(ldx_engine* e, int enable, int reset);
 int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap);
 /* Capture the planned forward into a hipGraph for replay (0 = eager launches). */
 int ldx_set_graph_mode(ldx_engine* e, int enable);
+
+/* ---- VAE decode and CLIP text encode (same ldx_engine handle type; load/finalize/destroy as above) ---------- */
+/* Keys for ldx_load_tensor: the reference's first_stage_model state dict ("decoder.*", "post_quant_conv.*"). */
+int ldx_vae_create(const ldx_vae_config* cfg, int device, ldx_engine** out);
+/* VAE.decode (VariationalAE.py:690-722): z [B][z_channels][h][w] fp32 (already divided by the latent scale) ->
+ * clamp((decoder(post_quant_conv(z)) + 1) / 2, 0, 1) as NHWC fp32 [B][8h][8w][3]. */
+int ldx_vae_decode(ldx_engine* e, const float* z_nchw, int B, int h, int w, float* out_nhwc, void* stream);
+/* Keys: the transformer's state dict with the "text_model." prefix stripped ("embeddings.token_embedding.weight",
+ * "encoder.layers.0.self_attn.q_proj.weight", ..., "final_layer_norm.weight"). */
+int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
+/* CLIPTextModel_.forward (src/clip/CLIPTextModel.py:51-107): ids [B][T] int32 -> out_last = final_layer_norm(x_L)
+ * [B][T][hidden] fp32; if out_inter != NULL, out_inter = final_layer_norm(x after layer `inter_layer`)
+ * (negative counts from the end, e.g. -2 = clip-skip 2; Clip.py:218-236).  Causal mask, no padding mask. */
+int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
+                    float* out_last, float* out_inter, void* stream);
 
 /* ---- sampler-side elementwise ops (src/sample/samplers.py, src/sample/CFG.py) ------------------ */
 /* d = lerp(den_uncond, den_cond, cfg) (CFG.py:60), then

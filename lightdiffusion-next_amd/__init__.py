@@ -12,6 +12,7 @@ Layout:
   weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
 """
 from . import lib, weights  # noqa: F401
-from .engine import UNetEngine, UNetConfig  # noqa: F401
+from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine  # noqa: F401
+from .weights import VAEConfig, CLIPConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
 from . import sampling  # noqa: F401

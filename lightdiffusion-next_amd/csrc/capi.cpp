@@ -65,6 +65,36 @@ int ldx_create(const ldx_unet_config* cfg, int device, ldx_engine** out) {
 }
 void ldx_destroy(ldx_engine* e) { if (e) { delete e->impl; delete e; } }
 
+int ldx_vae_create(const ldx_vae_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_vae_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    *out = new ldx_engine{new Engine(*cfg, device)};
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_clip_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    *out = new ldx_engine{new Engine(*cfg, device)};
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_vae_decode(ldx_engine* e, const float* z, int B, int h, int w, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_vae(z, B, h, w, out, (hipStream_t)stream);
+    GUARD_END
+}
+int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
+    GUARD_END
+}
 int ldx_load_tensor(ldx_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
@@ -80,18 +110,22 @@ int ldx_set_tables(ldx_engine* e, const float* log_sigmas, int n, const float* t
 int ldx_finalize(ldx_engine* e) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind == KIND_VAE) return e->impl->finalize_vae();
+    if (e->impl->kind == KIND_CLIP) return e->impl->finalize_clip();
     return e->impl->finalize();
     GUARD_END
 }
 int ldx_unet_denoise(ldx_engine* e, const float* x, const float* sigma, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise: not a UNet engine"); return LDX_ESTATE; }
     return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream);
     GUARD_END
 }
 int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_forward: not a UNet engine"); return LDX_ESTATE; }
     return e->impl->run(x, t, ctx, B2, h, w, M, out, false, (hipStream_t)stream);
     GUARD_END
 }
@@ -141,7 +175,7 @@ int ldx_op_convert(const float* in_f32, void* out_16, int64_t n, int dtype, int 
 }
 int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias, const float* rowvec, int rowvec_ld,
                 int rows_per_batch, int geglu, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream) {
-    if (!A || !W || M <= 0 || N <= 0 || K <= 0 || K % 64 || lda % 8 || (!C && !Cf)) { set_error("ldx_op_gemm: bad argument (K % 64, lda % 8)"); return LDX_EINVAL; }
+    if (!A || !W || M <= 0 || N <= 0 || K <= 0 || K % 8 || lda % 8 || (!C && !Cf)) { set_error("ldx_op_gemm: bad argument (K % 8, lda % 8)"); return LDX_EINVAL; }
     GemmArgs g{};
     g.A = A; g.lda = lda; g.W = W; g.M = M; g.N = N; g.K = K; g.mode = 0; g.bias = bias;
     g.rowvec = rowvec; g.rowvec_ld = rowvec_ld; g.rows_per_batch = rows_per_batch > 0 ? rows_per_batch : 1; g.geglu = geglu;

@@ -307,6 +307,7 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
 
 int Engine::finalize() {
     if (finalized) return LDX_OK;
+    if (kind != KIND_UNET) { set_error("finalize(): wrong engine kind"); return LDX_ESTATE; }
     int rc = validate();
     if (rc) return rc;
     HIP_OK(hipSetDevice(device));
@@ -510,12 +511,13 @@ void Engine::release(const Act& a) { if (a.valid && a.owned) a_free(a.off); }
 void Engine::emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W) {
     const int M = B * H * W;
     Act t1 = new_act(M, r.Cin);
-    op_gn("res.gn1", X, t1, B, H * W, r.gn1, 1e-5f, true);
+    op_gn("res.gn1", X, t1, B, H * W, r.gn1, r.eps, true);
     Act t2 = new_act(M, r.Cout);
-    op_conv("res.conv1", t1, B, H, W, r.Cin, r.conv1, 1, H, W, t2, Act{}, d_emb_all ? d_emb_all + r.emb_off : nullptr, emb_total);
+    if (r.has_emb) op_conv("res.conv1", t1, B, H, W, r.Cin, r.conv1, 1, H, W, t2, Act{}, d_emb_all ? d_emb_all + r.emb_off : nullptr, emb_total);
+    else op_conv("res.conv1", t1, B, H, W, r.Cin, r.conv1, 1, H, W, t2, Act{});
     release(t1);
     Act t3 = new_act(M, r.Cout);
-    op_gn("res.gn2", t2, t3, B, H * W, r.gn2, 1e-5f, true);
+    op_gn("res.gn2", t2, t3, B, H * W, r.gn2, r.eps, true);
     release(t2);
     if (r.has_skip) {
         Act t4 = new_act(M, r.Cout);
@@ -711,6 +713,60 @@ int Engine::plan(int B2, int h, int w, int Mc) {
     return LDX_OK;
 }
 
+int Engine::exec_ops(hipStream_t ls) {
+    const bool prof_now = profiling && !prof_graph;
+    if (prof_now && prof_events.size() < 2 * ops.size()) {
+        const size_t old = prof_events.size();
+        prof_events.resize(2 * ops.size());
+        for (size_t i = old; i < prof_events.size(); ++i) HIP_OK(hipEventCreate(&prof_events[i]));
+    }
+    size_t oi = 0;
+    for (const Op& o : ops) {
+        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi], ls));
+        switch (o.kind) {
+            case OP_PREP: {
+                PrepArgs p{};
+                p.x = b_x; p.sigma = b_s; p.B = pB2; p.C = cfg.in_channels; p.H = ph; p.W = pw; p.Cpad = 64;
+                p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
+                p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
+                p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s;
+                launch_prep(p, dt, ls);
+            } break;
+            case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
+            case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
+            case OP_GEMM: launch_gemm(o.g, dt, ls); break;
+            case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
+            case OP_LN: launch_layernorm(o.ln, dt, ls); break;
+            case OP_ATTN: launch_attention(o.at, dt, ls); break;
+            case OP_FINISH: {
+                FinishArgs f{};
+                f.eps = d_eps; f.ld = cfg.out_channels; f.x = b_den ? b_x : nullptr; f.sigma = b_s; f.out = b_out;
+                f.B = pB2; f.C = cfg.out_channels; f.HW = ph * pw;
+                launch_finish(f, ls);
+            } break;
+            case OP_VAEPREP: launch_vae_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, vae_pq, vae_pq ? vae_pq + o.i1 * o.i1 : nullptr, dt, ls); break;
+            case OP_SOFTMAX: launch_softmax_rows(o.p1, o.i0, o.i1, o.i2, o.f0, dt, ls); break;
+            case OP_CLAMP: launch_clamp01((const float*)o.p0, b_out, (size_t)o.i0, ls); break;
+            case OP_EMBED: launch_clip_embed(b_ids, clip_tok, clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
+            case OP_CVT_OUT: if ((o.i3 ? b_out2 : b_out) != nullptr) launch_t_to_f32(o.p0, o.i3 ? b_out2 : b_out, (size_t)o.i0, dt, ls); break;
+        }
+        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
+        ++oi;
+    }
+    if (prof_now) {
+        HIP_OK(hipStreamSynchronize(ls));
+        for (size_t i = 0; i < ops.size(); ++i) {
+            float ms = 0.f;
+            HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
+            const Op& o = ops[i];
+            std::string key = o.klabel[0] ? o.klabel : o.name;
+            ProfEntry& pe = prof[key];
+            pe.count += 1; pe.ms += ms; pe.flops += o.flops; pe.bytes += o.bytes;
+        }
+    }
+    return LDX_OK;
+}
+
 int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st) {
     if (!finalized) { set_error("ldx_unet_*: engine not finalized"); return LDX_ESTATE; }
     if (!x || !sigma_or_t || !ctx || !out || B2 <= 0 || h <= 0 || w <= 0 || Mc <= 0) { set_error("ldx_unet_*: bad argument"); return LDX_EINVAL; }
@@ -737,51 +793,9 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         ls = cap_stream;
     }
-    const bool prof_now = profiling && !use_graph;
-    if (prof_now && prof_events.size() < 2 * ops.size()) {
-        const size_t old = prof_events.size();
-        prof_events.resize(2 * ops.size());
-        for (size_t i = old; i < prof_events.size(); ++i) HIP_OK(hipEventCreate(&prof_events[i]));
-    }
-    size_t oi = 0;
-    for (const Op& o : ops) {
-        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi], ls));
-        switch (o.kind) {
-            case OP_PREP: {
-                PrepArgs p{};
-                p.x = x; p.sigma = sigma_or_t; p.B = B2; p.C = cfg.in_channels; p.H = h; p.W = w; p.Cpad = 64;
-                p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
-                p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
-                p.scale_input = denoise ? 1 : 0; p.t_in = denoise ? nullptr : sigma_or_t;
-                launch_prep(p, dt, ls);
-            } break;
-            case OP_CVT: launch_f32_to_t(ctx, o.cvt_out, o.cvt_n, dt, ls); break;
-            case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
-            case OP_GEMM: launch_gemm(o.g, dt, ls); break;
-            case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
-            case OP_LN: launch_layernorm(o.ln, dt, ls); break;
-            case OP_ATTN: launch_attention(o.at, dt, ls); break;
-            case OP_FINISH: {
-                FinishArgs f{};
-                f.eps = d_eps; f.ld = cfg.out_channels; f.x = denoise ? x : nullptr; f.sigma = sigma_or_t; f.out = out;
-                f.B = B2; f.C = cfg.out_channels; f.HW = h * w;
-                launch_finish(f, ls);
-            } break;
-        }
-        if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
-        ++oi;
-    }
-    if (prof_now) {
-        HIP_OK(hipStreamSynchronize(ls));
-        for (size_t i = 0; i < ops.size(); ++i) {
-            float ms = 0.f;
-            HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
-            const Op& o = ops[i];
-            std::string key = o.klabel[0] ? o.klabel : o.name;
-            ProfEntry& pe = prof[key];
-            pe.count += 1; pe.ms += ms; pe.flops += o.flops; pe.bytes += o.bytes;
-        }
-    }
+    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise;
+    prof_graph = use_graph;
+    { int rc = exec_ops(ls); if (rc) return rc; }
     if (use_graph) {
         hipGraph_t g = nullptr;
         HIP_OK(hipStreamEndCapture(cap_stream, &g));

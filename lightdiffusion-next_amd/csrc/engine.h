@@ -26,7 +26,8 @@ struct HostTensor {
 
 struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
-struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0; };
+struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0;
+              float eps = 1e-5f; bool has_emb = true; };
 struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; };
 struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };
 struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up = false; ResW res; XfW xf; LinearW down, up; int skip_ch = 0; };
@@ -34,20 +35,38 @@ struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up =
 // activation view inside the arena: rows x C 16-bit elements, row stride ld, starting at column col
 struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 0, C = 0, ld = 0, col = 0; };
 
-enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH };
+enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
+              OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT };
+enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2 };
 struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk;
     void* cvt_out; size_t cvt_n;
+    // generic slots for the small ops: src/dst pointers + dims
+    const void* p0; void* p1; int i0, i1, i2, i3; float f0;
     double flops; double bytes; char klabel[48];
 };
 struct ProfEntry { long count = 0; double ms = 0, flops = 0, bytes = 0; };
 
 struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
+struct VaeAttnW { NormW norm; LinearW q, k, v, proj; };
+struct ClipLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
+
 class Engine {
 public:
     Engine(const ldx_unet_config& c, int dev);
+    Engine(const ldx_vae_config& c, int dev);
+    Engine(const ldx_clip_config& c, int dev);
+    EngineKind kind = KIND_UNET;
+    ldx_vae_config vcfg{};
+    ldx_clip_config ccfg{};
+    int finalize_vae();
+    int finalize_clip();
+    int plan_vae(int B, int h, int w);
+    int plan_clip(int B, int T, int inter);
+    int run_vae(const float* z, int B, int h, int w, float* out_nhwc, hipStream_t st);
+    int run_clip(const int* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, hipStream_t st);
     ~Engine();
     int validate() const;
     int load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
@@ -85,6 +104,16 @@ private:
     bool mk_res(const std::string& pre, int Cin, int Cout, ResW& r);
     bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
 
+    int exec_ops(hipStream_t ls);
+    // per-call bindings read by exec_ops
+    const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false;
+    const int* b_ids = nullptr; float* b_out2 = nullptr;
+    // VAE
+    std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
+    ResW vae_mid1, vae_mid2; VaeAttnW vae_attn; NormW vae_norm_out; float* vae_pq = nullptr;
+    // CLIP
+    std::vector<ClipLayerW> clip_layers; NormW clip_final_ln; float* clip_tok = nullptr; float* clip_pos = nullptr;
+    int clip_inter_planned = -100;
     LinearW te0, te2, conv_in, conv_out, emb_all;
     NormW out_gn;
     std::vector<BlockW> in_blocks, out_blocks;
@@ -116,9 +145,12 @@ private:
     void op_ln(const char* name, Act X, Act Y, const NormW& n);
     void op_attn(const char* name, const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, Act O, int B, int H, int Nq, int Mk, int D);
     void emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W);
+    void emit_vae_attn(const VaeAttnW& a, Act X, Act OUT, int B, int H, int W);
+    bool mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r);
     void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc);
 
     std::vector<hipEvent_t> prof_events;
+    bool prof_graph = false;
     // graph replay
     hipGraphExec_t graph_exec = nullptr;
     hipStream_t cap_stream = nullptr;

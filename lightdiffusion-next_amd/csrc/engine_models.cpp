@@ -1,0 +1,327 @@
+// VAE decoder and CLIP text encoder on the same planner / kernels as the UNet (engine.cpp).
+//
+//   VAE   : Decoder.forward            src/AutoEncoders/VariationalAE.py:532-567
+//           ResnetBlock.forward        src/AutoEncoders/ResBlock.py:383-406      (GroupNorm eps 1e-6, swish)
+//           AttnBlock.forward          src/Attention/Attention.py:159-178        (1 head, D = C = 512)
+//           Upsample.forward           src/AutoEncoders/VariationalAE.py:209-221 (nearest 2x + conv3x3)
+//           AutoencodingEngine.decode  :130-145 (post_quant_conv) ; VAE.decode :690-722 (clamp, NHWC)
+//   CLIP  : CLIPTextModel_.forward     src/clip/CLIPTextModel.py:51-107
+//           CLIPLayer / CLIPAttention / CLIPMLP / CLIPEmbeddings   src/clip/Clip.py:14-294
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace ldx {
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return LDX_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+Engine::Engine(const ldx_vae_config& c, int dev) : cfg{}, device(dev) {
+    kind = KIND_VAE; vcfg = c;
+    dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
+}
+Engine::Engine(const ldx_clip_config& c, int dev) : cfg{}, device(dev) {
+    kind = KIND_CLIP; ccfg = c;
+    dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
+}
+
+// =============================================================================================
+// VAE
+bool Engine::mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r) {
+    r.Cin = Cin; r.Cout = Cout; r.eps = 1e-6f; r.has_emb = false;
+    if (!mk_norm(pre + ".norm1", Cin, r.gn1) || !mk_conv3(pre + ".conv1", Cout, Cin, Cin, r.conv1)) return false;
+    if (!mk_norm(pre + ".norm2", Cout, r.gn2) || !mk_conv3(pre + ".conv2", Cout, Cout, Cout, r.conv2)) return false;
+    r.has_skip = Cin != Cout;
+    if (r.has_skip && !mk_linear(pre + ".nin_shortcut", Cout, Cin, true, r.skip, true)) return false;
+    return true;
+}
+
+int Engine::finalize_vae() {
+    if (finalized) return LDX_OK;
+    const ldx_vae_config& v = vcfg;
+    auto bad = [&](const char* m) { set_error(std::string("unsupported VAE config: ") + m); return LDX_EINVAL; };
+    if (v.ch <= 0 || v.ch % 64) return bad("ch must be a multiple of 64");
+    if (v.num_levels < 1 || v.num_levels > 8 || v.z_channels < 1 || v.z_channels > 16 || v.out_ch < 1 || v.out_ch > 4) return bad("levels/channels");
+    HIP_OK(hipSetDevice(device));
+    bool ok = true;
+    int block_in = v.ch * v.ch_mult[v.num_levels - 1];
+    ok = ok && mk_conv3("decoder.conv_in", block_in, v.z_channels, 64, conv_in);
+    ok = ok && mk_vae_res("decoder.mid.block_1", block_in, block_in, vae_mid1);
+    ok = ok && mk_norm("decoder.mid.attn_1.norm", block_in, vae_attn.norm);
+    ok = ok && mk_linear("decoder.mid.attn_1.q", block_in, block_in, true, vae_attn.q, true);
+    ok = ok && mk_linear("decoder.mid.attn_1.k", block_in, block_in, true, vae_attn.k, true);
+    // v is used as the A operand (V^T = Wv . h^T); its bias is folded through the softmax (rows sum to 1)
+    // into the output projection's bias: b' = Wp . bv + bp.
+    ok = ok && mk_linear("decoder.mid.attn_1.v", block_in, block_in, false, vae_attn.v, true);
+    if (ok) {
+        const HostTensor* wp = get("decoder.mid.attn_1.proj_out.weight", {block_in, block_in, 1, 1});
+        const HostTensor* bp = get("decoder.mid.attn_1.proj_out.bias", {block_in});
+        const HostTensor* bv = get("decoder.mid.attn_1.v.bias", {block_in});
+        ok = wp && bp && bv;
+        if (ok) {
+            vae_attn.proj.N = block_in; vae_attn.proj.K = block_in;
+            vae_attn.proj.w = upload16(block_in, block_in, [&](size_t r, size_t c) { return wp->at(r * block_in + c); });
+            vae_attn.proj.b = upload32(block_in, [&](size_t i) {
+                double acc = bp->at(i);
+                for (int k = 0; k < block_in; ++k) acc += (double)wp->at(i * block_in + k) * (double)bv->at(k);
+                return (float)acc;
+            });
+            ok = vae_attn.proj.w && vae_attn.proj.b;
+        }
+    }
+    ok = ok && mk_vae_res("decoder.mid.block_2", block_in, block_in, vae_mid2);
+    vae_up.assign(v.num_levels, {}); vae_upconv.assign(v.num_levels, LinearW{}); vae_has_up.assign(v.num_levels, false);
+    for (int lv = v.num_levels - 1; ok && lv >= 0; --lv) {
+        const int block_out = v.ch * v.ch_mult[lv];
+        for (int i = 0; ok && i <= v.num_res_blocks; ++i) {
+            ResW r;
+            ok = mk_vae_res("decoder.up." + std::to_string(lv) + ".block." + std::to_string(i), block_in, block_out, r);
+            vae_up[lv].push_back(r);
+            block_in = block_out;
+        }
+        if (ok && lv != 0) {
+            vae_has_up[lv] = true;
+            ok = mk_conv3("decoder.up." + std::to_string(lv) + ".upsample.conv", block_in, block_in, block_in, vae_upconv[lv]);
+        }
+    }
+    ok = ok && mk_norm("decoder.norm_out", block_in, vae_norm_out) && mk_conv3("decoder.conv_out", v.out_ch, block_in, block_in, conv_out);
+    if (ok && v.use_post_quant) {
+        const HostTensor* w = get("post_quant_conv.weight", {v.z_channels, v.z_channels, 1, 1});
+        const HostTensor* b = get("post_quant_conv.bias", {v.z_channels});
+        ok = w && b;
+        if (ok) {
+            const int zc = v.z_channels;
+            vae_pq = upload32((size_t)zc * zc + zc, [&](size_t i) { return i < (size_t)zc * zc ? w->at(i) : b->at(i - (size_t)zc * zc); });
+            ok = vae_pq != nullptr;
+        }
+    }
+    if (!ok) {
+        if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
+        set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
+        return LDX_EHIP;
+    }
+    host.clear();
+    finalized = true;
+    return LDX_OK;
+}
+
+// AttnBlock: x + proj(softmax(q k^T / sqrt(C)) v), one head of width C, as three GEMMs + a row softmax
+void Engine::emit_vae_attn(const VaeAttnW& a, Act X, Act OUT, int B, int H, int W) {
+    const int N = H * W, M = B * N, C = a.q.N;
+    Act hn = new_act(M, C);
+    op_gn("vae.attn.norm", X, hn, B, N, a.norm, 1e-6f, false);
+    Act q = new_act(M, C), k = new_act(M, C);
+    op_gemm("vae.attn.q", hn, a.q, q, Act{});
+    op_gemm("vae.attn.k", hn, a.k, k, Act{});
+    Act o = new_act(M, C);
+    for (int b = 0; b < B; ++b) {
+        auto rows = [&](const Act& t, int r0, int nr) { Act v = t; v.owned = false; v.off = t.off + (size_t)r0 * t.ld * 2; v.rows = nr; return v; };
+        // V^T[C][N] = Wv[C][C] . hn_b[N][C]^T   (weights as the A operand, activations as "W")
+        Act vt = new_act(C, N);
+        { LinearW hw; hw.w = ptr(rows(hn, b * N, N)); hw.b = nullptr; hw.N = N; hw.K = C;
+          Act wv; wv.valid = true; wv.rows = C; wv.C = C; wv.ld = C; wv.off = 0; wv.col = 0;
+          Op oo{}; oo.kind = OP_GEMM; oo.name = "vae.attn.vT";
+          GemmArgs& g = oo.g; g.A = a.v.w; g.lda = C; g.W = hw.w; g.M = C; g.N = N; g.K = C; g.mode = 0; g.rows_per_batch = 1;
+          g.C = ptr(vt); g.ldc = N; g.splitk = 1;
+          oo.flops = 2.0 * C * (double)N * C; snprintf(oo.klabel, sizeof(oo.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
+          ops.push_back(oo); flops += oo.flops; (void)wv; }
+        // S[N][N] = q_b k_b^T
+        Act S = new_act(N, N);
+        { LinearW kw; kw.w = ptr(rows(k, b * N, N)); kw.b = nullptr; kw.N = N; kw.K = C;
+          op_gemm("vae.attn.qk", rows(q, b * N, N), kw, S, Act{}); }
+        { Op oo{}; oo.kind = OP_SOFTMAX; oo.name = "vae.attn.softmax"; oo.p1 = ptr(S); oo.i0 = N; oo.i1 = N; oo.i2 = N; oo.f0 = 1.0f / std::sqrt((float)C);
+          oo.bytes = 2.0 * 2.0 * N * (double)N; snprintf(oo.klabel, sizeof(oo.klabel), "softmax_rows"); ops.push_back(oo); }
+        // O_b[N][C] = P[N][N] . V[N][C]  with W = V^T[C][N]
+        { LinearW vw; vw.w = ptr(vt); vw.b = nullptr; vw.N = C; vw.K = N;
+          op_gemm("vae.attn.pv", S, vw, rows(o, b * N, N), Act{}); }
+        release(S); release(vt);
+    }
+    release(q); release(k); release(hn);
+    op_gemm("vae.attn.proj", o, a.proj, OUT, X);
+    release(o);
+}
+
+int Engine::plan_vae(int B, int h, int w) {
+    const ldx_vae_config& v = vcfg;
+    for (int pass = 0; pass < 2; ++pass) {
+        ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
+        if (pass == 1) {
+            if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
+            if (!arena) { HIP_OK(hipMalloc(&arena, arena_peak_dry)); arena_cap = arena_peak_dry; }
+        }
+        void* saved = arena;
+        if (pass == 0) arena = nullptr;
+        gn_ws_off = a_alloc((size_t)B * GN_NCHUNK * 32 * 2 * 4);
+        int H = h, W = w;
+        Act x0 = new_act(B * H * W, 64);
+        { Op o{}; o.kind = OP_VAEPREP; o.name = "vae.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = v.z_channels; o.i2 = H * W; o.i3 = 64; ops.push_back(o); }
+        int C = v.ch * v.ch_mult[v.num_levels - 1];
+        Act hcur = new_act(B * H * W, C);
+        op_conv("vae.conv_in", x0, B, H, W, 64, conv_in, 1, H, W, hcur, Act{});
+        flops -= 2.0 * B * H * W * (double)C * 9.0 * (64 - v.z_channels);
+        release(x0);
+        auto res = [&](const ResW& r) { Act o = new_act(B * H * W, r.Cout); emit_res(r, hcur, o, B, H, W); release(hcur); hcur = o; };
+        res(vae_mid1);
+        { Act o = new_act(B * H * W, C); emit_vae_attn(vae_attn, hcur, o, B, H, W); release(hcur); hcur = o; }
+        res(vae_mid2);
+        for (int lv = v.num_levels - 1; lv >= 0; --lv) {
+            for (auto& r : vae_up[lv]) res(r);
+            if (vae_has_up[lv]) {
+                const int Cc = vae_up[lv].back().Cout;
+                Act o = new_act(B * 2 * H * 2 * W, Cc);
+                op_conv("vae.up", hcur, B, H, W, Cc, vae_upconv[lv], 1, 2 * H, 2 * W, o, Act{});
+                release(hcur); hcur = o; H *= 2; W *= 2;
+            }
+        }
+        const int Cl = vae_up[0].back().Cout;
+        Act t = new_act(B * H * W, Cl);
+        op_gn("vae.norm_out", hcur, t, B, H * W, vae_norm_out, 1e-6f, true);
+        release(hcur);
+        const size_t o_pix = a_alloc((size_t)B * H * W * v.out_ch * 4);
+        float* pix = (float*)((uintptr_t)arena + o_pix);
+        op_conv("vae.conv_out", t, B, H, W, Cl, conv_out, 1, H, W, Act{}, Act{}, nullptr, 0, pix, v.out_ch);
+        release(t);
+        { Op o{}; o.kind = OP_CLAMP; o.name = "vae.clamp"; o.p0 = pix; o.i0 = B * H * W * v.out_ch; ops.push_back(o); }
+        if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
+    }
+    pB2 = B; ph = h; pw = w; pM = 0;
+    return LDX_OK;
+}
+
+int Engine::run_vae(const float* z, int B, int h, int w, float* out, hipStream_t st) {
+    if (!finalized || kind != KIND_VAE) { set_error("ldx_vae_decode: not a finalized VAE engine"); return LDX_ESTATE; }
+    if (!z || !out || B <= 0 || h <= 0 || w <= 0) { set_error("ldx_vae_decode: bad argument"); return LDX_EINVAL; }
+    if ((h * w) % 8) { set_error("ldx_vae_decode: h*w must be a multiple of 8 (attention row length)"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    if (B != pB2 || h != ph || w != pw) {
+        HIP_OK(hipStreamSynchronize(st));
+        int rc = plan_vae(B, h, w);
+        if (rc) return rc;
+    }
+    b_x = z; b_out = out; prof_graph = false;
+    int rc = exec_ops(st);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+// =============================================================================================
+// CLIP
+int Engine::finalize_clip() {
+    if (finalized) return LDX_OK;
+    const ldx_clip_config& c = ccfg;
+    auto bad = [&](const char* m) { set_error(std::string("unsupported CLIP config: ") + m); return LDX_EINVAL; };
+    if (c.hidden_size % 64 || c.intermediate_size % 64) return bad("hidden/intermediate size must be multiples of 64");
+    if (c.hidden_size % c.num_heads || (c.hidden_size / c.num_heads) % 8 || c.hidden_size / c.num_heads > 160) return bad("head dim");
+    HIP_OK(hipSetDevice(device));
+    const int E = c.hidden_size;
+    bool ok = true;
+    const HostTensor* tok = get("embeddings.token_embedding.weight", {c.vocab_size, E});
+    const HostTensor* pos = get("embeddings.position_embedding.weight", {c.max_positions, E});
+    ok = tok && pos;
+    if (ok) {
+        clip_tok = upload32((size_t)c.vocab_size * E, [&](size_t i) { return tok->at(i); });
+        clip_pos = upload32((size_t)c.max_positions * E, [&](size_t i) { return pos->at(i); });
+        ok = clip_tok && clip_pos;
+    }
+    clip_layers.resize(c.num_layers);
+    for (int l = 0; ok && l < c.num_layers; ++l) {
+        ClipLayerW& L = clip_layers[l];
+        const std::string p = "encoder.layers." + std::to_string(l);
+        ok = mk_norm(p + ".layer_norm1", E, L.ln1) && mk_norm(p + ".layer_norm2", E, L.ln2);
+        const HostTensor *qw = get(p + ".self_attn.q_proj.weight", {E, E}), *kw = get(p + ".self_attn.k_proj.weight", {E, E}),
+                         *vw = get(p + ".self_attn.v_proj.weight", {E, E}), *qb = get(p + ".self_attn.q_proj.bias", {E}),
+                         *kb = get(p + ".self_attn.k_proj.bias", {E}), *vb = get(p + ".self_attn.v_proj.bias", {E});
+        ok = ok && qw && kw && vw && qb && kb && vb;
+        if (ok) {
+            L.qkv.N = 3 * E; L.qkv.K = E;
+            L.qkv.w = upload16((size_t)3 * E, E, [&](size_t r, size_t cc) { const HostTensor* s = r < (size_t)E ? qw : (r < (size_t)2 * E ? kw : vw); return s->at((r % E) * E + cc); });
+            L.qkv.b = upload32((size_t)3 * E, [&](size_t i) { const HostTensor* s = i < (size_t)E ? qb : (i < (size_t)2 * E ? kb : vb); return s->at(i % E); });
+            ok = L.qkv.w && L.qkv.b;
+        }
+        ok = ok && mk_linear(p + ".self_attn.out_proj", E, E, true, L.out) && mk_linear(p + ".mlp.fc1", c.intermediate_size, E, true, L.fc1) &&
+             mk_linear(p + ".mlp.fc2", E, c.intermediate_size, true, L.fc2);
+    }
+    ok = ok && mk_norm("final_layer_norm", E, clip_final_ln);
+    if (!ok) {
+        if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
+        set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
+        return LDX_EHIP;
+    }
+    host.clear();
+    finalized = true;
+    return LDX_OK;
+}
+
+int Engine::plan_clip(int B, int T, int inter) {
+    const ldx_clip_config& c = ccfg;
+    const int E = c.hidden_size, M = B * T, heads = c.num_heads, D = E / heads;
+    for (int pass = 0; pass < 2; ++pass) {
+        ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
+        if (pass == 1) {
+            if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
+            if (!arena) { HIP_OK(hipMalloc(&arena, arena_peak_dry)); arena_cap = arena_peak_dry; }
+        }
+        void* saved = arena;
+        if (pass == 0) arena = nullptr;
+        Act x = new_act(M, E);
+        { Op o{}; o.kind = OP_EMBED; o.name = "clip.embed"; o.p1 = ptr(x); o.i0 = B; o.i1 = T; o.i2 = E; o.i3 = c.vocab_size; ops.push_back(o); }
+        Act n = new_act(M, E), qkv = new_act(M, 3 * E), a = new_act(M, E), f = new_act(M, c.intermediate_size);
+        Act xi = new_act(M, E);
+        for (int l = 0; l < c.num_layers; ++l) {
+            const ClipLayerW& L = clip_layers[l];
+            op_ln("clip.ln1", x, n, L.ln1);
+            op_gemm("clip.qkv", n, L.qkv, qkv, Act{});
+            const char* base = (const char*)ptr(qkv);
+            op_attn("clip.attn", base, 3 * E, base + (size_t)E * 2, 3 * E, base + (size_t)2 * E * 2, 3 * E, a, B, heads, T, T, D);
+            ops.back().at.causal = 1;
+            op_gemm("clip.out", a, L.out, x, x);                 // x += self_attn(ln1(x))
+            op_ln("clip.ln2", x, n, L.ln2);
+            op_gemm("clip.fc1", n, L.fc1, f, Act{});
+            ops.back().g.act = 1;                                // quick-GELU
+            op_gemm("clip.fc2", f, L.fc2, x, x);                 // x += mlp(ln2(x))
+            if (l == inter) {                                    // intermediate = x.clone(); final LN applied to it
+                op_ln("clip.final_ln.inter", x, xi, clip_final_ln);
+                Op o{}; o.kind = OP_CVT_OUT; o.name = "clip.out_inter"; o.p0 = ptr(xi); o.i0 = M * E; o.i3 = 1; ops.push_back(o);
+            }
+        }
+        op_ln("clip.final_ln", x, n, clip_final_ln);
+        { Op o{}; o.kind = OP_CVT_OUT; o.name = "clip.out_last"; o.p0 = ptr(n); o.i0 = M * E; o.i3 = 0; ops.push_back(o); }
+        if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
+    }
+    pB2 = B; ph = T; pw = 0; pM = 0; clip_inter_planned = inter;
+    return LDX_OK;
+}
+
+int Engine::run_clip(const int* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, hipStream_t st) {
+    if (!finalized || kind != KIND_CLIP) { set_error("ldx_clip_encode: not a finalized CLIP engine"); return LDX_ESTATE; }
+    if (!ids || !out_last || B <= 0 || T <= 0 || T > ccfg.max_positions) { set_error("ldx_clip_encode: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    int inter = -1;
+    if (out_inter) {
+        inter = inter_layer < 0 ? ccfg.num_layers + inter_layer : inter_layer;
+        if (inter < 0 || inter >= ccfg.num_layers) { set_error("ldx_clip_encode: inter_layer out of range"); return LDX_EINVAL; }
+    }
+    if (B != pB2 || T != ph || inter != clip_inter_planned) {
+        HIP_OK(hipStreamSynchronize(st));
+        int rc = plan_clip(B, T, inter);
+        if (rc) return rc;
+    }
+    b_ids = ids; b_out = out_last; b_out2 = out_inter; prof_graph = false;
+    int rc = exec_ops(st);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+}  // namespace ldx

@@ -44,7 +44,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int bid = lin % ntiles, split = lin / ntiles;      // same-split tiles adjacent: neighbours share panels
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk_all = p.K / BK;
+    const int nk_all = (p.K + BK - 1) / BK;      // K % 8 == 0; a ragged last K-tile is zero-filled by the loader
     const int kt_begin = (int)((long)split * nk_all / S), kt_end = (int)((long)(split + 1) * nk_all / S);
     const int nk = kt_end - kt_begin;
 
@@ -109,9 +109,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     };
     auto gload = [&](int kt) {
         const int k0 = (kt_begin + kt) * BK;
+        // ragged last K-tile (plain GEMM only; conv has K = 9*Cin, Cin % 64 == 0): chunks past K read as 0
+        const bool kdead = (k0 + BK > p.K) && (k0 + schunk * 8 >= p.K);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, a_voff[j], k0 * 2);
+            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
         } else {
             if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             if (st_ci >= p.Cin) { st_ci = 0; st_new_tap = true; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) rb[j] = ld128(rW, w_voff[j], k0 * 2);
+        for (int j = 0; j < NJ; ++j) rb[j] = ld128(rW, kdead ? OOB : w_voff[j], k0 * 2);
     };
     auto lstore = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;
@@ -221,6 +223,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (full) {
                     if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                     if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                    }
                     if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
                     if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -229,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                         float x = v[r];
                         if (p.bias) x += p.bias[n + r];
                         if (rv) x += rv[n + r];
+                        if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
                         if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
                         if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
                         if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             float x = v[r];
             if (p.bias) x += p.bias[n + r];
             if (rv) x += rv[n + r];
+            if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
             if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
             v[r] = x;
         }
@@ -327,7 +335,7 @@ int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int nk = K / BK;
-    if (tiles >= 200 || nk < 12) return 1;
+    if (tiles >= 200 || nk < 12 || K % BK) return 1;
     int s = 560 / tiles;
     if (s > nk / 5) s = nk / 5;
     if (s > 16) s = 16;

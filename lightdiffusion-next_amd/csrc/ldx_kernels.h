@@ -33,6 +33,7 @@ struct GemmArgs {
     const float* bias;             // [N] or null
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
     int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2
+    int act;                       // 0 none, 1 quick-GELU x*sigmoid(1.702x) after bias (CLIP MLP, clip/Clip.py:74-77)
     const void* R; int ldr;        // residual (16-bit) or null
     void* C; int ldc;              // 16-bit output or null
     float* Cf; int ldcf;           // fp32 output or null
@@ -102,6 +103,16 @@ void launch_f32_to_t(const float* in, void* out, size_t n, DType dt, hipStream_t
 void launch_t_to_f32(const void* in, float* out, size_t n, DType dt, hipStream_t s);
 // NCHW fp32 <-> NHWC 16-bit (VAE boundary)
 void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int Cpad, float scale, DType dt, hipStream_t s);
+
+// VAE boundary (AutoEncoders/VariationalAE.py:130-145, 690-722): z fp32 NCHW [B][C][HW] -> optional 1x1 mix
+// (post_quant_conv, fp32: out[c] = b[c] + sum_k w[c][k] z[k]) -> NHWC 16-bit with Cpad channels.
+void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, const float* mix_w, const float* mix_b, DType dt, hipStream_t s);
+// pixel post-process: out = clamp((x + 1) / 2, 0, 1) on fp32 (process_output, VariationalAE.py:595-597)
+void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s);
+// row softmax in place on a 16-bit [rows][ld] matrix: p = softmax(x * scale) (VAE AttnBlock, D = 512 single head)
+void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType dt, hipStream_t s);
+// CLIP embeddings (clip/Clip.py:254-294): x[b][t][:] = tok[id[b][t]][:] + pos[t][:]  (fp32 tables -> 16-bit)
+void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int T, int C, int vocab, DType dt, hipStream_t s);
 
 // Sampler elementwise kernels (fp32, reference samplers.py / CFG.py):
 //  d = lerp(den_uncond, den_cond, cfg)                             (torch.lerp, CFG.py:60)

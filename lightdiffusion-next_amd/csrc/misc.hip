@@ -133,6 +133,105 @@ void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int C
     else hipLaunchKernelGGL((nchw_to_nhwc_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, in, (_Float16*)out, B, C, HW, Cpad, scale);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void vae_prep_kernel(const float* z, T* out, int B, int C, int HW, int Cpad, const float* mw, const float* mb) {
+    const int cpp = Cpad / 8;
+    const long total = (long)B * HW * cpp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % cpp);
+        const long bp = idx / cpp;
+        const int pix = (int)(bp % HW), b = (int)(bp / HW);
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            float v = 0.f;
+            if (c < C) {
+                if (mw) {
+                    v = mb ? mb[c] : 0.f;
+                    for (int k = 0; k < C; ++k) v += mw[c * C + k] * z[((long)b * C + k) * HW + pix];
+                } else v = z[((long)b * C + c) * HW + pix];
+            }
+            f[e] = v;
+        }
+        *(uint4*)(out + ((long)b * HW + pix) * Cpad + ch * 8) = pack8<T>(f);
+    }
+}
+void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, const float* mw, const float* mb, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * HW * (Cpad / 8);
+    if (dt == DT_BF16) hipLaunchKernelGGL((vae_prep_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, z, (__bf16*)out, B, C, HW, Cpad, mw, mb);
+    else hipLaunchKernelGGL((vae_prep_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, z, (_Float16*)out, B, C, HW, Cpad, mw, mb);
+}
+
+__global__ __launch_bounds__(256) void clamp01_kernel(const float* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
+        out[i] = fminf(fmaxf((in[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
+}
+void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(clamp01_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+}
+
+// one workgroup per row; three passes over the (L2-resident) row: max, sum of exp, normalise
+template <typename T>
+__global__ __launch_bounds__(256) void softmax_rows_kernel(T* X, int cols, int ld, float scale) {
+    __shared__ float red[4];
+    T* __restrict__ x = X + (long)blockIdx.x * ld;
+    const int tid = threadIdx.x, nch = cols >> 3;
+    const float c = scale * 1.44269504088896340736f;
+    float mx = -INFINITY;
+    for (int ch = tid; ch < nch; ch += 256) {
+        float f[8]; unpack8<T>(*(const uint4*)(x + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) mx = fmaxf(mx, f[e]);
+    }
+    mx = wave_max(mx);
+    if ((tid & 63) == 0) red[tid >> 6] = mx;
+    __syncthreads();
+    mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+    __syncthreads();
+    float sum = 0.f;
+    for (int ch = tid; ch < nch; ch += 256) {
+        float f[8]; unpack8<T>(*(const uint4*)(x + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) sum += __builtin_amdgcn_exp2f((f[e] - mx) * c);
+    }
+    sum = wave_sum(sum);
+    if ((tid & 63) == 0) red[tid >> 6] = sum;
+    __syncthreads();
+    const float inv = 1.0f / (red[0] + red[1] + red[2] + red[3]);
+    for (int ch = tid; ch < nch; ch += 256) {
+        float f[8]; unpack8<T>(*(const uint4*)(x + ch * 8), f);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = __builtin_amdgcn_exp2f((f[e] - mx) * c) * inv;
+        *(uint4*)(x + ch * 8) = pack8<T>(f);
+    }
+}
+void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL((softmax_rows_kernel<__bf16>), dim3(rows), dim3(256), 0, s, (__bf16*)X, cols, ld, scale);
+    else hipLaunchKernelGGL((softmax_rows_kernel<_Float16>), dim3(rows), dim3(256), 0, s, (_Float16*)X, cols, ld, scale);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const float* tok, const float* pos, T* out, int B, int Tn, int C, int vocab) {
+    const long total = (long)B * Tn * (C / 8);
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % (C / 8));
+        const long bt = idx / (C / 8);
+        const int t = (int)(bt % Tn);
+        int id = ids[bt];
+        id = max(0, min(id, vocab - 1));
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) f[e] = tok[(long)id * C + ch * 8 + e] + pos[(long)t * C + ch * 8 + e];
+        *(uint4*)(out + bt * C + ch * 8) = pack8<T>(f);
+    }
+}
+void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int Tn, int C, int vocab, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * Tn * (C / 8);
+    if (dt == DT_BF16) hipLaunchKernelGGL((clip_embed_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (__bf16*)out, B, Tn, C, vocab);
+    else hipLaunchKernelGGL((clip_embed_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (_Float16*)out, B, Tn, C, vocab);
+}
+
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs p) {
     // Same operation order (and no FMA contraction) as the reference's fp32 tensor expressions.

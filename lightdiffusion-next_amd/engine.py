@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import lib
-from .weights import UNetConfig
+from .weights import UNetConfig, VAEConfig, CLIPConfig
 
 
 def sd15_sigmas():
@@ -120,3 +120,113 @@ class UNetEngine:
         n, f, a = C.c_int64(), C.c_double(), C.c_int64()
         lib.check(self._lib.ldx_plan_info(self._h, C.byref(n), C.byref(f), C.byref(a)), "ldx_plan_info")
         return {"launches": n.value, "flops": f.value, "arena_bytes": a.value}
+
+
+def _load_state_dict(L, h, state_dict, strip=()):
+    for k, t in state_dict.items():
+        for pre in strip:
+            if k.startswith(pre):
+                k = k[len(pre):]
+        t = t.detach().to("cpu").contiguous()
+        if t.dtype not in (torch.float16, torch.bfloat16, torch.float32):
+            t = t.float()
+        shape = (C.c_int64 * t.dim())(*t.shape)
+        lib.check(L.ldx_load_tensor(h, k.encode(), lib.ptr(t), lib.torch_dtype_code(t.dtype), shape, t.dim()),
+                  f"ldx_load_tensor({k})")
+
+
+class VAEDecoderEngine:
+    """VAE.decode (src/AutoEncoders/VariationalAE.py:690-722): latent (already / 0.18215) -> NHWC fp32 in [0, 1]."""
+
+    def __init__(self, cfg: VAEConfig, state_dict, device: int = 0, dtype: str = "bf16"):
+        self._lib = lib.load()
+        self._h = C.c_void_p()
+        self.cfg, self.device = cfg, torch.device("cuda", device)
+        c = lib.ldx_vae_config()
+        c.compute_dtype = {"bf16": lib.LDX_BF16, "f16": lib.LDX_F16, "fp16": lib.LDX_F16}[dtype]
+        c.z_channels, c.ch, c.num_levels = cfg.z_channels, cfg.ch, len(cfg.ch_mult)
+        for i, v in enumerate(cfg.ch_mult):
+            c.ch_mult[i] = v
+        c.num_res_blocks, c.out_ch, c.use_post_quant = cfg.num_res_blocks, cfg.out_ch, int(cfg.use_post_quant)
+        lib.check(self._lib.ldx_vae_create(C.byref(c), device, C.byref(self._h)), "ldx_vae_create")
+        _load_state_dict(self._lib, self._h, state_dict, strip=("first_stage_model.",))
+        lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+
+    def decode(self, z):
+        assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 4
+        b, _, h, w = z.shape
+        out = torch.empty((b, 8 * h, 8 * w, self.cfg.out_ch), device=z.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_vae_decode(self._h, lib.ptr(z.contiguous()), b, h, w, lib.ptr(out), lib.current_stream_ptr()),
+                  "ldx_vae_decode")
+        return out
+
+    profile = UNetEngine.profile
+    profile_report = UNetEngine.profile_report
+    plan_info = UNetEngine.plan_info
+    close = UNetEngine.close
+    __del__ = UNetEngine.__del__
+
+
+class CLIPTextEngine:
+    """CLIPTextModel_.forward (src/clip/CLIPTextModel.py:51-107) + the token-weight logic of
+    ClipTokenWeightEncoder.encode_token_weights (src/SD15/SDClip.py:36-97) on the host."""
+
+    def __init__(self, cfg: CLIPConfig, state_dict, device: int = 0, dtype: str = "bf16"):
+        self._lib = lib.load()
+        self._h = C.c_void_p()
+        self.cfg, self.device = cfg, torch.device("cuda", device)
+        c = lib.ldx_clip_config()
+        c.compute_dtype = {"bf16": lib.LDX_BF16, "f16": lib.LDX_F16, "fp16": lib.LDX_F16}[dtype]
+        c.hidden_size, c.num_layers, c.num_heads = cfg.hidden_size, cfg.num_layers, cfg.num_heads
+        c.intermediate_size, c.max_positions, c.vocab_size = cfg.intermediate_size, cfg.max_positions, cfg.vocab_size
+        lib.check(self._lib.ldx_clip_create(C.byref(c), device, C.byref(self._h)), "ldx_clip_create")
+        _load_state_dict(self._lib, self._h, {k: v for k, v in state_dict.items() if "text_projection" not in k},
+                         strip=("text_model.",))
+        lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+        tp = state_dict.get("text_projection.weight")
+        self.text_projection = None if tp is None else tp.float().to(self.device)
+
+    def forward(self, tokens, intermediate_output=None):
+        """tokens: int tensor [B][T] -> (last [B,T,E] after final LN, intermediate (final-LN'd) or None, pooled)."""
+        ids = tokens.to(self.device, torch.int32).contiguous()
+        b, t = ids.shape
+        last = torch.empty((b, t, self.cfg.hidden_size), device=self.device, dtype=torch.float32)
+        inter = torch.empty_like(last) if intermediate_output is not None else None
+        lib.check(self._lib.ldx_clip_encode(self._h, lib.ptr(ids), b, t, int(intermediate_output or 0), lib.ptr(last),
+                                            lib.ptr(inter), lib.current_stream_ptr()), "ldx_clip_encode")
+        # pooled output: row at argmax(tokens == eos_token_id) (CLIPTextModel.py:98-106; eos id 2 -> position 0 quirk)
+        pos = (ids == self.cfg.eos_token_id).int().argmax(dim=-1)
+        pooled = last[torch.arange(b, device=self.device), pos]
+        if self.text_projection is not None:                   # CLIPTextModel.forward (CLIPTextModel.py:146-150); [B,E] host-side plumbing
+            pooled = pooled @ self.text_projection.t()
+        return last, inter, pooled
+
+    def encode_token_weights(self, token_weight_pairs, layer_idx=-2, special_tokens=(49406, 49407, 49407)):
+        """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) for a list of 77-token (id, weight) chunks."""
+        to_encode, has_weights, max_len = [], False, 0
+        for x in token_weight_pairs:
+            toks = [a[0] for a in x]
+            max_len = max(max_len, len(toks))
+            has_weights = has_weights or not all(a[1] == 1.0 for a in x)
+            to_encode.append(toks)
+        sections = len(to_encode)
+        if has_weights or sections == 0:
+            start, end, pad = special_tokens
+            to_encode.append([start, end] + [pad] * (max_len - 2))           # gen_empty_tokens (SDClip.py:10-20)
+        last, inter, pooled = self.forward(torch.tensor(to_encode, dtype=torch.int64), intermediate_output=layer_idx)
+        out = (inter if layer_idx is not None else last).float().cpu()
+        output = []
+        for k in range(sections):
+            z = out[k:k + 1].clone()
+            if has_weights:
+                z_empty = out[-1]
+                for j in range(z.shape[1]):
+                    wgt = token_weight_pairs[k][j][1]
+                    if wgt != 1.0:
+                        z[0][j] = (z[0][j] - z_empty[j]) * wgt + z_empty[j]
+            output.append(z)
+        cond = out[-1:] if not output else torch.cat(output, dim=-2)
+        return cond, pooled[0:1].float().cpu()
+
+    close = UNetEngine.close
+    __del__ = UNetEngine.__del__

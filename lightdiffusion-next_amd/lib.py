@@ -33,6 +33,16 @@ class ldx_unet_config(C.Structure):
     ]
 
 
+class ldx_vae_config(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("z_channels", C.c_int32), ("ch", C.c_int32), ("num_levels", C.c_int32),
+                ("ch_mult", C.c_int32 * 8), ("num_res_blocks", C.c_int32), ("out_ch", C.c_int32), ("use_post_quant", C.c_int32)]
+
+
+class ldx_clip_config(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("hidden_size", C.c_int32), ("num_layers", C.c_int32), ("num_heads", C.c_int32),
+                ("intermediate_size", C.c_int32), ("max_positions", C.c_int32), ("vocab_size", C.c_int32)]
+
+
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _SIGS = {
     "ldx_version": (C.c_char_p, []),
@@ -48,6 +58,10 @@ _SIGS = {
     "ldx_profile": (_i, [_vp, _i, _i]),
     "ldx_profile_report": (_i, [_vp, C.c_char_p, _i64]),
     "ldx_set_graph_mode": (_i, [_vp, _i]),
+    "ldx_vae_create": (_i, [C.POINTER(ldx_vae_config), _i, C.POINTER(_vp)]),
+    "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
+    "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ldx_sampler_step": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
     "ldx_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ldx_op_convert": (_i, [_vp, _vp, _i64, _i, _i, _vp]),

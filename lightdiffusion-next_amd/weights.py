@@ -172,3 +172,91 @@ def param_count(spec) -> int:
             m *= d
         n += m
     return n
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class VAEConfig:
+    """ddconfig of the SD1.5 AutoencoderKL (src/AutoEncoders/VariationalAE.py:612-640)."""
+
+    z_channels: int = 4
+    ch: int = 128
+    ch_mult: Tuple[int, ...] = (1, 2, 4, 4)
+    num_res_blocks: int = 2
+    out_ch: int = 3
+    use_post_quant: bool = True
+
+    @staticmethod
+    def tiny(ch: int = 64) -> "VAEConfig":
+        return VAEConfig(ch=ch)
+
+
+def vae_decoder_state_dict_spec(cfg: VAEConfig):
+    """Decoder + post_quant_conv keys in the order Decoder.__init__ creates them (VariationalAE.py:416-530)."""
+    spec = []
+
+    def res(pre, cin, cout):
+        nonlocal spec
+        spec += [(f"{pre}.norm1.weight", (cin,)), (f"{pre}.norm1.bias", (cin,)),
+                 (f"{pre}.conv1.weight", (cout, cin, 3, 3)), (f"{pre}.conv1.bias", (cout,)),
+                 (f"{pre}.norm2.weight", (cout,)), (f"{pre}.norm2.bias", (cout,)),
+                 (f"{pre}.conv2.weight", (cout, cout, 3, 3)), (f"{pre}.conv2.bias", (cout,))]
+        if cin != cout:
+            spec += [(f"{pre}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{pre}.nin_shortcut.bias", (cout,))]
+
+    nl = len(cfg.ch_mult)
+    block_in = cfg.ch * cfg.ch_mult[-1]
+    spec += [("decoder.conv_in.weight", (block_in, cfg.z_channels, 3, 3)), ("decoder.conv_in.bias", (block_in,))]
+    res("decoder.mid.block_1", block_in, block_in)
+    spec += [("decoder.mid.attn_1.norm.weight", (block_in,)), ("decoder.mid.attn_1.norm.bias", (block_in,))]
+    for n in ("q", "k", "v", "proj_out"):
+        spec += [(f"decoder.mid.attn_1.{n}.weight", (block_in, block_in, 1, 1)), (f"decoder.mid.attn_1.{n}.bias", (block_in,))]
+    res("decoder.mid.block_2", block_in, block_in)
+    for lv in reversed(range(nl)):
+        block_out = cfg.ch * cfg.ch_mult[lv]
+        for i in range(cfg.num_res_blocks + 1):
+            res(f"decoder.up.{lv}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lv != 0:
+            spec += [(f"decoder.up.{lv}.upsample.conv.weight", (block_in, block_in, 3, 3)),
+                     (f"decoder.up.{lv}.upsample.conv.bias", (block_in,))]
+    spec += [("decoder.norm_out.weight", (block_in,)), ("decoder.norm_out.bias", (block_in,)),
+             ("decoder.conv_out.weight", (cfg.out_ch, block_in, 3, 3)), ("decoder.conv_out.bias", (cfg.out_ch,))]
+    if cfg.use_post_quant:
+        spec += [("post_quant_conv.weight", (cfg.z_channels, cfg.z_channels, 1, 1)), ("post_quant_conv.bias", (cfg.z_channels,))]
+    return spec
+
+
+@dataclass
+class CLIPConfig:
+    """include/clip/sd1_clip_config.json as read by CLIPTextModel_ (src/clip/CLIPTextModel.py:3-50)."""
+
+    hidden_size: int = 768
+    num_layers: int = 12
+    num_heads: int = 12
+    intermediate_size: int = 3072
+    max_positions: int = 77
+    vocab_size: int = 49408
+    eos_token_id: int = 2          # the include/ json says 2 (not 49407): pooled output quirk, SURVEY A-9
+
+    @staticmethod
+    def tiny() -> "CLIPConfig":
+        return CLIPConfig(hidden_size=128, num_layers=3, num_heads=2, intermediate_size=256, vocab_size=49408)
+
+
+def clip_state_dict_spec(cfg: CLIPConfig):
+    """text_model.* keys (prefix stripped) of CLIPTextModel_ (CLIPTextModel.py:25-50, Clip.py:14-294)."""
+    e, f = cfg.hidden_size, cfg.intermediate_size
+    spec = [("embeddings.token_embedding.weight", (cfg.vocab_size, e)),
+            ("embeddings.position_embedding.weight", (cfg.max_positions, e))]
+    for l in range(cfg.num_layers):
+        p = f"encoder.layers.{l}"
+        spec += [(f"{p}.layer_norm1.weight", (e,)), (f"{p}.layer_norm1.bias", (e,))]
+        for n in ("q_proj", "k_proj", "v_proj", "out_proj"):
+            spec += [(f"{p}.self_attn.{n}.weight", (e, e)), (f"{p}.self_attn.{n}.bias", (e,))]
+        spec += [(f"{p}.layer_norm2.weight", (e,)), (f"{p}.layer_norm2.bias", (e,)),
+                 (f"{p}.mlp.fc1.weight", (f, e)), (f"{p}.mlp.fc1.bias", (f,)),
+                 (f"{p}.mlp.fc2.weight", (e, f)), (f"{p}.mlp.fc2.bias", (e,))]
+    spec += [("final_layer_norm.weight", (e,)), ("final_layer_norm.bias", (e,))]
+    spec += [("text_projection.weight", (e, e))]       # CLIPTextModel.text_projection (CLIPTextModel.py:126-128), no prefix
+    return spec

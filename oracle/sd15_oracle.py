@@ -377,3 +377,117 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
 
     x = fn(model, x, sigmas, trace=trace, **extra)
     return x / 0.18215                                                                    # CFG.py:294
+
+
+# ---------------------------------------------------------------------------------------------------
+# VAE decode  (src/AutoEncoders/VariationalAE.py, src/AutoEncoders/ResBlock.py:341-406, src/Attention/Attention.py:127-178)
+def vae_resnet_block(w, x):
+    """ResnetBlock.forward (ResBlock.py:383-406): Normalize = GroupNorm(32, eps 1e-6) (Attention.py:11-31), swish."""
+    h = F.conv2d(F.silu(group_norm(x, w, "norm1", 1e-6)), w("conv1.weight"), w("conv1.bias"), padding=1)
+    h = F.conv2d(F.silu(group_norm(h, w, "norm2", 1e-6)), w("conv2.weight"), w("conv2.bias"), padding=1)
+    if w.has("nin_shortcut.weight"):
+        x = F.conv2d(x, w("nin_shortcut.weight"), w("nin_shortcut.bias"))
+    return x + h
+
+
+def vae_attn_block(w, x):
+    """AttnBlock.forward (Attention.py:159-178) with pytorch_attention (AttentionMethods.py:175-197): one head of width C."""
+    h = group_norm(x, w, "norm", 1e-6)
+    q = F.conv2d(h, w("q.weight"), w("q.bias"))
+    k = F.conv2d(h, w("k.weight"), w("k.bias"))
+    v = F.conv2d(h, w("v.weight"), w("v.bias"))
+    b, c, hh, ww = q.shape
+    q, k, v = (t.view(b, 1, c, -1).transpose(2, 3).contiguous() for t in (q, k, v))
+    out = F.scaled_dot_product_attention(q, k, v, attn_mask=None, dropout_p=0.0, is_causal=False)
+    out = out.transpose(2, 3).reshape(b, c, hh, ww)
+    return x + F.conv2d(out, w("proj_out.weight"), w("proj_out.bias"))
+
+
+def vae_decode(sd, cfg, z):
+    """VAE.decode (VariationalAE.py:690-722) -> AutoencodingEngine.decode (:130-145) -> Decoder.forward (:532-567);
+    process_output clamp((x+1)/2, 0, 1) (:595-597); returns NHWC fp32."""
+    w = W(sd)
+    h = z.float()
+    if cfg.use_post_quant:
+        h = F.conv2d(h, w("post_quant_conv.weight"), w("post_quant_conv.bias"))
+    d = w.sub("decoder.")
+    h = F.conv2d(h, d("conv_in.weight"), d("conv_in.bias"), padding=1)
+    h = vae_resnet_block(d.sub("mid.block_1."), h)
+    h = vae_attn_block(d.sub("mid.attn_1."), h)
+    h = vae_resnet_block(d.sub("mid.block_2."), h)
+    nl = len(cfg.ch_mult)
+    for lv in reversed(range(nl)):
+        for i in range(cfg.num_res_blocks + 1):
+            h = vae_resnet_block(d.sub(f"up.{lv}.block.{i}."), h)
+        if lv != 0:
+            h = F.interpolate(h, scale_factor=2.0, mode="nearest")                        # Upsample VariationalAE.py:209-221
+            h = F.conv2d(h, d(f"up.{lv}.upsample.conv.weight"), d(f"up.{lv}.upsample.conv.bias"), padding=1)
+    h = F.silu(group_norm(h, d, "norm_out", 1e-6))
+    h = F.conv2d(h, d("conv_out.weight"), d("conv_out.bias"), padding=1)
+    return torch.clamp((h + 1.0) / 2.0, min=0.0, max=1.0).movedim(1, -1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# CLIP text encoder  (src/clip/CLIPTextModel.py:51-107, src/clip/Clip.py:14-294, src/SD15/SDClip.py:36-97)
+def clip_forward(sd, cfg, tokens, intermediate_output=None, final_layer_norm_intermediate=True):
+    """CLIPTextModel_.forward: returns (x after final LN, intermediate (final-LN'd) or None, pooled)."""
+    w = W(sd)
+    e, heads = cfg.hidden_size, cfg.num_heads
+    x = F.embedding(tokens, w("embeddings.token_embedding.weight")) + w("embeddings.position_embedding.weight")[: tokens.shape[1]]
+    mask = torch.empty(x.shape[1], x.shape[1], dtype=x.dtype).fill_(float("-inf")).triu_(1)     # causal (CLIPTextModel.py:83-91)
+    if intermediate_output is not None and intermediate_output < 0:
+        intermediate_output = cfg.num_layers + intermediate_output                            # Clip.py:222-224
+    inter = None
+    for l in range(cfg.num_layers):
+        lw = w.sub(f"encoder.layers.{l}.")
+        n = F.layer_norm(x, (e,), lw("layer_norm1.weight"), lw("layer_norm1.bias"))
+        q = F.linear(n, lw("self_attn.q_proj.weight"), lw("self_attn.q_proj.bias"))
+        k = F.linear(n, lw("self_attn.k_proj.weight"), lw("self_attn.k_proj.bias"))
+        v = F.linear(n, lw("self_attn.v_proj.weight"), lw("self_attn.v_proj.bias"))
+        b = q.shape[0]
+        qh, kh, vh = (t.view(b, -1, heads, e // heads).transpose(1, 2) for t in (q, k, v))
+        a = F.scaled_dot_product_attention(qh, kh, vh, attn_mask=mask, dropout_p=0.0, is_causal=False)
+        a = a.transpose(1, 2).reshape(b, -1, e)
+        x = x + F.linear(a, lw("self_attn.out_proj.weight"), lw("self_attn.out_proj.bias"))
+        n = F.layer_norm(x, (e,), lw("layer_norm2.weight"), lw("layer_norm2.bias"))
+        hdn = F.linear(n, lw("mlp.fc1.weight"), lw("mlp.fc1.bias"))
+        hdn = hdn * torch.sigmoid(1.702 * hdn)                                                # quick_gelu Clip.py:74-77
+        x = x + F.linear(hdn, lw("mlp.fc2.weight"), lw("mlp.fc2.bias"))
+        if l == intermediate_output:
+            inter = x.clone()
+    x = F.layer_norm(x, (e,), w("final_layer_norm.weight"), w("final_layer_norm.bias"))
+    if inter is not None and final_layer_norm_intermediate:
+        inter = F.layer_norm(inter, (e,), w("final_layer_norm.weight"), w("final_layer_norm.bias"))
+    pos = (tokens == cfg.eos_token_id).int().argmax(dim=-1)                                   # CLIPTextModel.py:98-106
+    pooled = x[torch.arange(x.shape[0]), pos]
+    if w.has("text_projection.weight"):                                                       # CLIPTextModel.forward :146-150
+        pooled = F.linear(pooled, w("text_projection.weight"))
+    return x, inter, pooled
+
+
+def clip_encode_token_weights(sd, cfg, token_weight_pairs, layer_idx=-2, special_tokens=(49406, 49407, 49407)):
+    """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) + SDClipModel.forward (:269-336)."""
+    to_encode, has_weights, max_len = [], False, 0
+    for x in token_weight_pairs:
+        toks = [a[0] for a in x]
+        max_len = max(max_len, len(toks))
+        has_weights = has_weights or not all(a[1] == 1.0 for a in x)
+        to_encode.append(toks)
+    sections = len(to_encode)
+    if has_weights or sections == 0:
+        start, end, pad = special_tokens
+        to_encode.append([start, end] + [pad] * (max_len - 2))
+    last, inter, pooled = clip_forward(sd, cfg, torch.LongTensor(to_encode), intermediate_output=layer_idx)
+    out = (inter if layer_idx is not None else last).float()
+    output = []
+    for k in range(sections):
+        z = out[k:k + 1].clone()
+        if has_weights:
+            z_empty = out[-1]
+            for j in range(z.shape[1]):
+                wgt = token_weight_pairs[k][j][1]
+                if wgt != 1.0:
+                    z[0][j] = (z[0][j] - z_empty[j]) * wgt + z_empty[j]
+        output.append(z)
+    cond = out[-1:] if not output else torch.cat(output, dim=-2)
+    return cond, pooled[0:1]

@@ -42,7 +42,7 @@ def _st():
 
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("M,N,K,lda_extra", [(300, 200, 128, 0), (1024, 320, 320, 64), (154, 640, 768, 0), (32768, 320, 320, 0), (513, 4, 2880 // 64 * 64, 0),
-                                              (2048, 1280, 1280, 0), (512, 1280, 2560, 0)])   # last three take the split-K path
+                                              (2048, 1280, 1280, 0), (512, 1280, 2560, 0), (200, 96, 96, 0), (130, 64, 200, 8)])   # last three take the split-K path
 def test_gemm(L, ldx, dt, M, N, K, lda_extra):
     td, code = DT[dt]
     g = torch.Generator(device="cuda").manual_seed(M + N + K)
