@@ -95,7 +95,7 @@ def main():
     g = torch.Generator().manual_seed(7)
     pos = torch.randn([1, 77, cfg.context_dim], generator=g)
     neg = torch.randn([1, 77, cfg.context_dim], generator=g)
-    noise = ldx.sampling.prepare_noise(torch.zeros(world, 4, lat, lat), 42)[rank:rank + 1]    # config-3 style shard
+    noise = ldx.parallel.shard_noise((world, 4, lat, lat), 42, rank, world)                   # config-3 style shard
     x = (noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)).to(dev)
     model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, 1, lat, lat)
 
@@ -113,10 +113,8 @@ def main():
     t0 = time.perf_counter()
     ev0.record()
     run_steps(args.warmup, args.steps)
-    gathered = None
-    if dist:
-        gathered = [torch.empty_like(x) for _ in range(world)]
-        dist.all_gather(gathered, x)                           # final latents only
+    gathered = ldx.parallel.gather_latents(x, world, dist)    # final latents only: the job's single collective
+    assert gathered.shape[0] == world
     ev1.record()
     torch.cuda.synchronize()
     if dist:
@@ -172,7 +170,7 @@ def main():
             "metric": "sampler it/s (UNet steps/sec) SD1.5 1024x1024 bs=1 bf16",
             "value": round(value, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": round(value / 2.8, 3), "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": (round(value / 2.8, 3) if world == 1 else None), "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SD1.5 UNet (859.5M params, synthetic seeded weights) sampler loop, latent "
                                    f"[1,4,{lat},{lat}] ({lat * 8}x{lat * 8}), CFG batch 2, ctx 77x768, sample_euler/normal, "
                                    f"multiscale off; per-GPU bs=1, {world} image(s) in flight",

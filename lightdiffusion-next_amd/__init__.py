@@ -9,10 +9,11 @@ Layout:
   engine.py    UNetEngine: weights in, denoise out (device pointers through the C ABI)
   hook.py      LdxUNetPatch: drop-in for model_options["model_function_wrapper"] (cond.py:254-263)
   sampling.py  host mirror of src/sample (schedulers, CFG batching, Euler / DPM++ loops)
+  parallel.py  batch shard + single all-gather across the GPUs of a node (RCCL / gloo)
   weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
 """
 from . import lib, weights  # noqa: F401
 from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine  # noqa: F401
 from .weights import VAEConfig, CLIPConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
-from . import sampling  # noqa: F401
+from . import sampling, parallel  # noqa: F401

@@ -335,7 +335,8 @@ int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
     const int nk = K / BK;
-    if (tiles >= 200 || nk < 12 || K % BK) return 1;
+    // a split costs a second (reduce) launch of ~9 us: only worth it for long K (3x3 convs, FF down-projection)
+    if (tiles >= 200 || nk < 40 || K % BK) return 1;
     int s = 560 / tiles;
     if (s > nk / 5) s = nk / 5;
     if (s > 16) s = 16;
