@@ -18,16 +18,20 @@
 
 namespace ldx {
 
-constexpr int BM = 128, BK = 64;
+constexpr int BK = 64;
 // BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
 // 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)
 // that N = 320 / 960 / 1920 get with 128.
-template <int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
+template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
 
-template <typename T, int MODE, int BN>
+// BM x BN workgroup tile, 4 waves as 2x2, each wave (BM/2) x (BN/2) = MI x NJ MFMA tiles of 16x16.
+// 128x128 / 128x160 for large problems; 64x64 for short-K problems whose 128-wide tiling would leave most CUs
+// idle (they are latency-bound: 4-5x more, smaller workgroups hide the HBM/L2 latency with thread-level parallelism).
+template <typename T, int MODE, int BM, int BN>
 __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
-    constexpr int NJ = BN / 32;                 // 16-column MFMA tiles per wave (wave = 64 x BN/2)
-    constexpr int STAGE_BYTES = stage_bytes<BN>();
+    constexpr int MI = BM / 32;                 // 16-row MFMA tiles per wave
+    constexpr int NJ = BN / 32;                 // 16-column MFMA tiles per wave
+    constexpr int STAGE_BYTES = stage_bytes<BM, BN>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
 
@@ -68,11 +72,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ap + a_base), 0, (int)(a_rem > 0x7fffffffL ? 0x7fffffffL : a_rem), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.K), 0, (int)(w_rem > 0x7fffffffL ? 0x7fffffffL : w_rem), 0x00020000);
 
-    int a_voff[4];                    // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
-    int a_pix[4];                     // conv: byte offset of this row's batch image + chunk
-    int a_oy[4], a_ox[4];
+    int a_voff[MI];                   // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
+    int a_pix[MI];                    // conv: byte offset of this row's batch image + chunk
+    int a_oy[MI], a_ox[MI];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < MI; ++j) {
         const int m = m0 + srow + 32 * j;
         const bool ok = m < p.M;
         if (MODE == 0) {
@@ -96,7 +100,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
     const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
 
-    uint4 ra[4], rb[NJ];
+    uint4 ra[MI], rb[NJ];
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
     bool st_new_tap = true;
     if (MODE == 1 && kt_begin > 0) {
@@ -113,11 +117,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const bool kdead = (k0 + BK > p.K) && (k0 + schunk * 8 >= p.K);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
+            for (int j = 0; j < MI; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
         } else {
             if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
+                for (int j = 0; j < MI; ++j) {
                     int iy = a_oy[j] + st_ky, ix = a_ox[j] + st_kx;
                     const bool ok = a_pix[j] != OOB && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
                     if (p.resize) {   // nearest: src = min(floor(dst * in/out), in-1)  (torch upsample_nearest)
@@ -129,7 +133,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             }
             const int soff = st_ci * 2;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) ra[j] = ld128(rA, a_voff[j], soff);
+            for (int j = 0; j < MI; ++j) ra[j] = ld128(rA, a_voff[j], soff);
             st_ci += BK;
             st_new_tap = false;
             if (st_ci >= p.Cin) { st_ci = 0; st_new_tap = true; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
@@ -141,17 +145,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         char* sA = smem + stage * STAGE_BYTES;
         char* sB = sA + BM * BK * 2;
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) {
+        for (int j = 0; j < (MI > NJ ? MI : NJ); ++j) {
             const int row = srow + 32 * j;
             const int off = row * 128 + ((schunk ^ (row & 7)) << 4);
-            if (j < 4) *(uint4*)(sA + off) = ra[j < 4 ? j : 0];
-            *(uint4*)(sB + off) = rb[j];
+            if (j < MI) *(uint4*)(sA + off) = ra[j < MI ? j : 0];
+            if (j < NJ) *(uint4*)(sB + off) = rb[j < NJ ? j : 0];
         }
     };
 
-    f32x4 acc[4][NJ];
+    f32x4 acc[MI][NJ];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
@@ -167,10 +171,10 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            V8 af[4], bf[NJ];
+            V8 af[MI], bf[NJ];
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int row = wm * 64 + i * 16 + l15;
+            for (int i = 0; i < MI; ++i) {
+                const int row = wm * (BM / 2) + i * 16 + l15;
                 const int ch = (ks * 4 + g4) ^ (row & 7);
                 af[i] = as_v8<T>(*(const uint4*)(sA + row * 128 + (ch << 4)));
             }
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 bf[j] = as_v8<T>(*(const uint4*)(sB + row * 128 + (ch << 4)));
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MI; ++i)
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
         }
@@ -193,8 +197,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     if (S > 1) {
         float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int m = m0 + wm * 64 + i * 16 + l15;
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -209,11 +213,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const T* __restrict__ Rp = (const T*)p.R;
     T* __restrict__ Cp = (T*)p.C;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int m = m0 + wm * 64 + i * 16 + l15;
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
         if (m >= p.M) continue;
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
-        if (BN != 128 || !p.geglu) {
+        if (BN != 128 || BM != 128 || !p.geglu) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     }
                 }
             }
-        } else if (BN == 128) {
+        } else if (BN == 128 && BM == 128) {
             // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -251,7 +255,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (ng >= p.N) continue;
                 const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                constexpr int JG = (BN == 128) ? 2 : 0;
+                constexpr int JG = (BN == 128 && BM == 128) ? 2 : 0;
                 float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
                 if (p.bias) {
                     const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
@@ -305,23 +309,40 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
-static inline int gemm_bn(const GemmArgs& a) { return (!a.geglu && a.N % 160 == 0 && a.N % 128 != 0) ? 160 : 128; }
+// tile selection: {BM, BN}
+struct TileSel { int bm, bn; };
+static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
+    if (geglu) return {128, 128};
+    const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+    const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn) * (splitk > 1 ? splitk : 1);
+    // < 0.8 of one round of 2 workgroups x 256 CUs and a short K loop (latency-bound): go small.
+    // Long-K problems (3x3 convs) keep the big tile: measured 112 us (128x128) vs 125 us (64x64) at 64^2, 640->640;
+    // 2048x1280x1280 went 27.6 -> 18.8 us with 64x64.
+    if (tiles < 400 && K <= 24 * BK) return {64, 64};
+    return {128, bn};
+}
 
-template <typename T, int MODE, int BN>
+template <typename T, int MODE, int BM, int BN>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
-    const size_t lds = 2 * stage_bytes<BN>();
+    const size_t lds = 2 * stage_bytes<BM, BN>();
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((gemm_kernel<T, MODE, BN>), dim3(tiles), dim3(256), lds, s, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN>), dim3(tiles), dim3(256), lds, s, a);
+}
+
+template <typename T, int MODE>
+static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
+    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
+    if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);
+    else if (t.bn == 160) launch_gemm_inst<T, MODE, 128, 160>(a, S, s);
+    else launch_gemm_inst<T, MODE, 128, 128>(a, S, s);
 }
 
 template <typename T>
 static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int S = (a.splitk > 1 && a.ws && !a.geglu) ? a.splitk : 1;
-    const bool wide = gemm_bn(a) == 160;
-    if (a.mode == 0) { if (wide) launch_gemm_inst<T, 0, 160>(a, S, s); else launch_gemm_inst<T, 0, 128>(a, S, s); }
-    else             { if (wide) launch_gemm_inst<T, 1, 160>(a, S, s); else launch_gemm_inst<T, 1, 128>(a, S, s); }
+    if (a.mode == 0) launch_gemm_mode<T, 0>(a, S, s); else launch_gemm_mode<T, 1>(a, S, s);
     if (S > 1) {
         long total = (long)a.M * ((a.N + 3) / 4);
         int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
@@ -333,7 +354,7 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     if (geglu) return 1;
     const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
-    const int tiles = ((M + BM - 1) / BM) * ((N + bn - 1) / bn);
+    const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
     const int nk = K / BK;
     // a split costs a second (reduce) launch of ~9 us: only worth it for long K (3x3 convs, FF down-projection)
     if (tiles >= 200 || nk < 40 || K % BK) return 1;
