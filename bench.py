@@ -151,9 +151,17 @@ def main():
                 e["alg_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
             kern[k] = e
         dom = next(k for k in kern if "tflops" in kern[k])
+        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*/traffic.json), if any
+        traffic = None
+        try:
+            import glob
+            tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))[-1]
+            traffic = json.load(open(tj)).get(dom, {}).get("bytes")
+        except Exception:
+            traffic = None
         step_ms_gpu = ev0.elapsed_time(ev1) / args.steps
         roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(kern[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": None,
+                "frac": round(kern[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "avg_launch_ms": round(kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1), 4),
                 "step_tflop": round(info["flops"] / 1e12, 4),
                 "step_achieved": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12, 2),
