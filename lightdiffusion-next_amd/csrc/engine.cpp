@@ -283,12 +283,10 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         const HostTensor* k2 = get(bp + ".attn2.to_k.weight", {C, ctx});
         const HostTensor* v2 = get(bp + ".attn2.to_v.weight", {C, ctx});
         if (!k2 || !v2) return false;
-        b.kv2.N = 2 * C; b.kv2.K = ctx; b.kv2.b = nullptr;
-        b.kv2.w = upload16((size_t)2 * C, ctx, [&](size_t r, size_t c) {
-            const HostTensor* s = r < (size_t)C ? k2 : v2;
-            return s->at((r % C) * ctx + c);
-        });
-        if (!b.kv2.w) return false;
+        b.kv2.N = 2 * C; b.kv2.K = ctx; b.kv2.b = nullptr; b.kv2.w = nullptr;
+        b.kv_off = kv_total;                       // columns [kv_off, kv_off + 2C) of the batched k|v projection
+        kv_total += 2 * C;
+        kv_srcs.push_back({k2, v2, C});
         if (!mk_linear(bp + ".attn2.to_out.0", C, C, true, b.o2)) return false;
         // GEGLU projection: rows permuted so each 64-column slab holds 32 value rows then their 32 gate rows
         const int inner = 4 * C;
@@ -379,12 +377,24 @@ int Engine::finalize() {
         emb_all.b = upload32(emb_total, [&](size_t r) { const size_t i = find(r); return emb_srcs[i].b->at(r - starts[i]); });
         ok = emb_all.w && emb_all.b;
     }
+    if (ok && kv_total > 0) {
+        std::vector<size_t> starts; size_t acc = 0;
+        for (auto& s2 : kv_srcs) { starts.push_back(acc); acc += 2 * (size_t)s2.C; }
+        const int ctxd = cfg.context_dim;
+        kv_all.N = kv_total; kv_all.K = ctxd; kv_all.b = nullptr;
+        kv_all.w = upload16(kv_total, ctxd, [&](size_t r, size_t c) {
+            const size_t i = std::upper_bound(starts.begin(), starts.end(), r) - starts.begin() - 1;
+            const size_t rr = r - starts[i]; const int C = kv_srcs[i].C;
+            return (rr < (size_t)C ? kv_srcs[i].k : kv_srcs[i].v)->at((rr % C) * ctxd + c);
+        });
+        ok = kv_all.w != nullptr;
+    }
     if (!ok) {
         if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
         set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
         return LDX_EHIP;
     }
-    emb_srcs.clear();
+    emb_srcs.clear(); kv_srcs.clear();
     host.clear();
     finalized = true;
     return LDX_OK;
@@ -552,11 +562,10 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         op_ln("xf.ln2", h, n, b.ln2);
         Act q = new_act(M, C);
         op_gemm("xf.q2", n, b.q2, q, Act{});
-        Act kv = new_act(B * Mc, 2 * C);
-        op_gemm("xf.kv2", ctx16, b.kv2, kv, Act{});
-        const char* kvb = (const char*)ptr(kv);
-        op_attn("xf.attn2", ptr(q), C, kvb, 2 * C, kvb + (size_t)C * 2, 2 * C, a, B, heads, H * W, Mc, D);
-        release(q); release(kv);
+        // k|v of the context come from the one batched projection emitted at the start of the forward
+        const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
+        op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
+        release(q);
         op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
         release(a);
         op_ln("xf.ln3", h, n, b.ln3);
@@ -620,6 +629,9 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.2"; o.sk = SkinnyArgs{d_e1, ted, te2.w, te2.b, d_e2, ted, B2, ted, ted, 0, 1}; ops.push_back(o); }
         { Op o{}; o.kind = OP_SKINNY; o.name = "emb_layers"; o.sk = SkinnyArgs{d_e2, ted, emb_all.w, emb_all.b, d_emb_all, emb_total, B2, emb_total, ted, 0, 0}; ops.push_back(o); }
         flops += 2.0 * B2 * ((double)ted * mc + (double)ted * ted + (double)emb_total * ted);
+        Act kvall = new_act(B2 * Mc, kv_total);
+        kv_all_off = kvall.off;
+        op_gemm("xf.kv2_all", ctx16, kv_all, kvall, Act{});
 
         int lv = 0, s = 0;
         Act hcur = skip_view(0);
@@ -705,7 +717,7 @@ int Engine::plan(int B2, int h, int w, int Mc) {
             release(t);
         }
         { Op o{}; o.kind = OP_FINISH; o.name = "finish"; ops.push_back(o); }
-        release(ctx16);
+        release(ctx16); release(kvall);
         if (!bind) { arena_peak_dry = arena_peak; arena = saved_arena; }
     }
     pB2 = B2; ph = h; pw = w; pM = Mc;

@@ -28,7 +28,7 @@ struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0;
               float eps = 1e-5f; bool has_emb = true; };
-struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; };
+struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_off = 0; };
 struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };
 struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up = false; ResW res; XfW xf; LinearW down, up; int skip_ch = 0; };
 
@@ -122,6 +122,9 @@ private:
     XfW mid_xf;
     int emb_total = 0;
     std::vector<EmbSrc> emb_srcs;
+    // all cross-attention k|v projections of the context, batched into one GEMM per forward
+    struct KvSrc { const HostTensor* k; const HostTensor* v; int C; };
+    std::vector<KvSrc> kv_srcs; int kv_total = 0; LinearW kv_all; size_t kv_all_off = 0;
     float* d_log_sigmas = nullptr; float* d_temb = nullptr; int n_sigmas = 0;
 
     // plan

@@ -84,3 +84,7 @@ if __name__ == "__main__":
         conv(); conv(H=64, Cin=640, Cout=640); conv(H=32, Cin=1280, Cout=1280); conv(H=16, Cin=1280, Cout=1280); conv(H=16, Cin=2560, Cout=1280)
     if what in ("gn", "all"):
         gn(); gn(HW=4096, Cn=640); gn(HW=1024, Cn=1280); gn(HW=256, Cn=2560)
+    if what == "ksweep":
+        for (M, N) in ((32768, 320), (8192, 640), (2048, 1280)):
+            for K in (64, 128, 320, 640, 1280, 2560):
+                gemm(M, N, K)
