@@ -74,6 +74,21 @@ typedef struct ldx_clip_config {
     int32_t vocab_size;             /* 49408 */
 } ldx_clip_config;
 
+/* Flux DiT — FluxParams (src/BlackForest/Flux.py:293-306); flux-dev: 16, 768, 4096, 3072, 4.0, 24, 19, 38,
+ * axes [16,56,56], theta 10000, qkv_bias 1, guidance_embed 1. */
+typedef struct ldx_flux_config {
+    int32_t compute_dtype;
+    int32_t in_channels;          /* latent channels (16); tokens carry 4x that after the 2x2 patchify */
+    int32_t vec_in_dim;           /* 768  (pooled CLIP-L) */
+    int32_t context_in_dim;       /* 4096 (T5-XXL) ; multiple of 8 */
+    int32_t hidden_size;          /* 3072 ; multiple of 64 */
+    int32_t mlp_hidden;           /* int(hidden_size * mlp_ratio) = 12288 ; multiple of 64 */
+    int32_t num_heads;            /* 24 ; head dim = hidden/heads in {16,32,64,128} */
+    int32_t depth;                /* 19 double-stream blocks */
+    int32_t depth_single;         /* 38 single-stream blocks */
+    int32_t guidance_embed;       /* 1 */
+} ldx_flux_config;
+
 /* ---- lifecycle -------------------------------------------------------------------------------- */
 const char* ldx_version(void);
 const char* ldx_last_error(void);
@@ -128,6 +143,18 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
  * (negative counts from the end, e.g. -2 = clip-skip 2; Clip.py:218-236).  Causal mask, no padding mask. */
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
+
+/* ---- Flux DiT ------------------------------------------------------------------------------ */
+/* Keys for ldx_load_tensor: Flux3's state dict ("img_in.weight", "double_blocks.0.img_mod.lin.weight", ...). */
+int ldx_flux_create(const ldx_flux_config* cfg, int device, ldx_engine** out);
+/* Flux3.forward (Flux.py:732-778) behind BaseModel.apply_model with CONST prediction (sampling.py:100-155):
+ *   denoise != 0: out = x - Flux3(x, t = sigma, ctx, y, guidance) * sigma ; denoise == 0: raw model output.
+ *   x [B][C][h][w] fp32 (h, w even), sigma [B], ctx [B][Lt][context_in_dim], y [B][vec_in_dim], guidance [B] (may be
+ *   NULL when guidance_embed == 0); pe_cos / pe_sin: [Lt + h*w/4][head_dim/2] fp32 rotary tables the host builds
+ *   with the reference's rope() (Flux.py:36-70) for ids = [txt_ids ; img_ids]. */
+int ldx_flux_forward(ldx_engine* e, const float* x, const float* sigma, const float* ctx, const float* y,
+                     const float* guidance, const float* pe_cos, const float* pe_sin,
+                     int B, int h, int w, int Lt, int denoise, float* out, void* stream);
 
 /* ---- sampler-side elementwise ops (src/sample/samplers.py, src/sample/CFG.py) ------------------ */
 /* d = lerp(den_uncond, den_cond, cfg) (CFG.py:60), then

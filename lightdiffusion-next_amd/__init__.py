@@ -13,7 +13,7 @@ Layout:
   weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
 """
 from . import lib, weights  # noqa: F401
-from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine  # noqa: F401
-from .weights import VAEConfig, CLIPConfig  # noqa: F401
+from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine, FluxEngine  # noqa: F401
+from .weights import VAEConfig, CLIPConfig, FluxConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
 from . import sampling, parallel  # noqa: F401

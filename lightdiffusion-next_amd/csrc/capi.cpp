@@ -95,6 +95,22 @@ int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_l
     return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_flux_create(const ldx_flux_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_flux_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    *out = new ldx_engine{new Engine(*cfg, device)};
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_flux_forward(ldx_engine* e, const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,
+                     const float* pe_cos, const float* pe_sin, int B, int h, int w, int Lt, int denoise, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_flux(x, sigma, ctx, y, guidance, pe_cos, pe_sin, B, h, w, Lt, denoise != 0, out, (hipStream_t)stream);
+    GUARD_END
+}
 int ldx_load_tensor(ldx_engine* e, const char* key, const void* data, int dtype, const int64_t* shape, int ndim) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
@@ -112,6 +128,7 @@ int ldx_finalize(ldx_engine* e) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     if (e->impl->kind == KIND_VAE) return e->impl->finalize_vae();
     if (e->impl->kind == KIND_CLIP) return e->impl->finalize_clip();
+    if (e->impl->kind == KIND_FLUX) return e->impl->finalize_flux();
     return e->impl->finalize();
     GUARD_END
 }
@@ -208,7 +225,7 @@ int ldx_op_groupnorm(const void* X, int ldx_, void* Y, int ldy, int B, int HW, i
     return check_launch("ldx_op_groupnorm");
 }
 int ldx_op_layernorm(const void* X, int ldx_, void* Y, int ldy, int rows, int C, float eps, const float* gamma, const float* beta, int dtype, void* stream) {
-    if (!X || !Y || !gamma || !beta || C % 8 || C > 2048) { set_error("ldx_op_layernorm: bad argument (C % 8, C <= 2048)"); return LDX_EINVAL; }
+    if (!X || !Y || !gamma || !beta || C % 8 || C > 3072) { set_error("ldx_op_layernorm: bad argument (C % 8, C <= 3072)"); return LDX_EINVAL; }
     LayerNormArgs a{X, ldx_, Y, ldy, rows, C, eps, gamma, beta};
     launch_layernorm(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_layernorm");

@@ -761,6 +761,14 @@ int Engine::exec_ops(hipStream_t ls) {
             case OP_CLAMP: launch_clamp01((const float*)o.p0, b_out, (size_t)o.i0, ls); break;
             case OP_EMBED: launch_clip_embed(b_ids, clip_tok, clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
             case OP_CVT_OUT: if ((o.i3 ? b_out2 : b_out) != nullptr) launch_t_to_f32(o.p0, o.i3 ? b_out2 : b_out, (size_t)o.i0, dt, ls); break;
+            case OP_FX_TEMB: launch_flux_temb(o.i0 ? b_guid : b_s, (float*)o.p1, pB2, 256, 1000.0f, ls); break;
+            case OP_FX_SILU: launch_silu_f32((const float*)o.p0, (float*)o.p1, (size_t)o.i0, ls); break;
+            case OP_FX_PATCH: launch_flux_patchify(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
+            case OP_FX_CVT_CTX: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
+            case OP_FX_SKINNY_Y: { SkinnyArgs a = o.sk; a.x = b_y; launch_skinny(a, dt, ls); } break;
+            case OP_FX_SKINNY_G: break;
+            case OP_FX_ROPE: { QkRopeArgs a = o.rp; const int hp = a.D / 2; a.cosT = b_cos + (size_t)o.i0 * hp; a.sinT = b_sin + (size_t)o.i0 * hp; launch_qk_norm_rope(a, dt, ls); } break;
+            case OP_FX_UNPATCH: launch_flux_unpatchify(fx_tok, 4 * o.i1, b_den ? b_x : nullptr, b_s, b_out, o.i0, o.i1, o.i2, o.i3, ls); break;
         }
         if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
         ++oi;

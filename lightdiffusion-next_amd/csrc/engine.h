@@ -36,11 +36,12 @@ struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up =
 struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 0, C = 0, ld = 0, col = 0; };
 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
-              OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT };
-enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2 };
+              OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G };
+enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3 };
 struct Op {
     OpKind kind; const char* name;
-    GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk;
+    GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp;
     void* cvt_out; size_t cvt_n;
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0;
@@ -52,12 +53,21 @@ struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
 struct VaeAttnW { NormW norm; LinearW q, k, v, proj; };
 struct ClipLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
+struct FluxStreamW { LinearW qkv, proj, mlp0, mlp2; float* qs = nullptr; float* ks = nullptr; int mod_off = 0; };
+struct FluxDoubleW { FluxStreamW img, txt; };
+struct FluxSingleW { LinearW lin1_qkv, lin1_mlp, lin2; float* qs = nullptr; float* ks = nullptr; int mod_off = 0; };
 
 class Engine {
 public:
     Engine(const ldx_unet_config& c, int dev);
     Engine(const ldx_vae_config& c, int dev);
     Engine(const ldx_clip_config& c, int dev);
+    Engine(const ldx_flux_config& c, int dev);
+    ldx_flux_config fcfg{};
+    int finalize_flux();
+    int plan_flux(int B, int h, int w, int Lt);
+    int run_flux(const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,
+                 const float* pe_cos, const float* pe_sin, int B, int h, int w, int Lt, bool denoise, float* out, hipStream_t st);
     EngineKind kind = KIND_UNET;
     ldx_vae_config vcfg{};
     ldx_clip_config ccfg{};
@@ -111,6 +121,13 @@ private:
     // VAE
     std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
     ResW vae_mid1, vae_mid2; VaeAttnW vae_attn; NormW vae_norm_out; float* vae_pq = nullptr;
+    // Flux
+    std::vector<FluxDoubleW> fx_double; std::vector<FluxSingleW> fx_single;
+    LinearW fx_img_in, fx_txt_in, fx_time0, fx_time1, fx_vec0, fx_vec1, fx_gd0, fx_gd1, fx_mod_all, fx_final;
+    int fx_mod_total = 0, fx_final_mod_off = 0;
+    std::vector<EmbSrc> fx_mod_srcs;
+    const float *b_y = nullptr, *b_guid = nullptr, *b_cos = nullptr, *b_sin = nullptr;
+    float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
     // CLIP
     std::vector<ClipLayerW> clip_layers; NormW clip_final_ln; float* clip_tok = nullptr; float* clip_pos = nullptr;
     int clip_inter_planned = -100;

@@ -1,0 +1,269 @@
+// Flux DiT on the shared planner / kernels.
+//
+//   Flux3.forward / forward_orig     src/BlackForest/Flux.py:658-778  (2x2 patchify, img/txt ids, blocks, LastLayer)
+//   DoubleStreamBlock.forward        :298-348    SingleStreamBlock.forward :389-418    LastLayer.forward :455-471
+//   Modulation :231-257, QKNorm/RMSNorm :148-200, attention + apply_rope :18-82, MLPEmbedder :105-131
+//   timestep_embedding_flux          src/sample/sampling_util.py:78-104
+//   CONST (flow) prediction          src/sample/sampling.py:100-155 (input unscaled, t = sigma, denoised = x - out*sigma)
+//
+// Layout: one joint token buffer X[B][Lt + Li][C] (txt rows first, then img rows) so the concat before the
+// single-stream blocks (Flux.py:711) is free; every per-stream op addresses a row slice of it.  All 19*2 + 38 + 1
+// adaLN modulation projections are one batched skinny GEMM on SiLU(vec) per forward.
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+#include "engine.h"
+
+namespace ldx {
+
+#define HIP_OK(expr)                                                                         \
+    do {                                                                                     \
+        hipError_t _e = (expr);                                                              \
+        if (_e != hipSuccess) {                                                              \
+            set_error(std::string(#expr) + ": " + hipGetErrorString(_e));                    \
+            return LDX_EHIP;                                                                 \
+        }                                                                                    \
+    } while (0)
+
+Engine::Engine(const ldx_flux_config& c, int dev) : cfg{}, device(dev) {
+    kind = KIND_FLUX; fcfg = c;
+    dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
+}
+
+int Engine::finalize_flux() {
+    if (finalized) return LDX_OK;
+    const ldx_flux_config& f = fcfg;
+    auto bad = [&](const char* m) { set_error(std::string("unsupported Flux config: ") + m); return LDX_EINVAL; };
+    const int C = f.hidden_size, H = f.num_heads;
+    if (C <= 0 || C % 64 || f.mlp_hidden % 64 || C > 3072) return bad("hidden_size / mlp_hidden must be multiples of 64, hidden <= 3072");
+    if (H <= 0 || C % H) return bad("hidden_size % num_heads");
+    const int D = C / H;
+    if (!(D == 16 || D == 32 || D == 64 || D == 128)) return bad("head dim must be 16, 32, 64 or 128");
+    if (f.context_in_dim % 8 || f.vec_in_dim % 8 || (4 * f.in_channels) % 8) return bad("input dims must be multiples of 8");
+    HIP_OK(hipSetDevice(device));
+    bool ok = true;
+    const int inC = 4 * f.in_channels;
+    ok = ok && mk_linear("img_in", C, inC, true, fx_img_in) && mk_linear("txt_in", C, f.context_in_dim, true, fx_txt_in);
+    ok = ok && mk_linear("time_in.in_layer", C, 256, true, fx_time0) && mk_linear("time_in.out_layer", C, C, true, fx_time1);
+    ok = ok && mk_linear("vector_in.in_layer", C, f.vec_in_dim, true, fx_vec0) && mk_linear("vector_in.out_layer", C, C, true, fx_vec1);
+    if (f.guidance_embed) ok = ok && mk_linear("guidance_in.in_layer", C, 256, true, fx_gd0) && mk_linear("guidance_in.out_layer", C, C, true, fx_gd1);
+    auto scale_vec = [&](const std::string& key, float*& out) {
+        const HostTensor* t = get(key, {D});
+        if (!t) return false;
+        out = upload32(D, [&](size_t i) { return t->at(i); });
+        return out != nullptr;
+    };
+    auto add_mod = [&](const std::string& pre, int mult, int& off) {
+        const HostTensor* w = get(pre + ".weight", {mult * C, C});
+        const HostTensor* b = get(pre + ".bias", {mult * C});
+        if (!w || !b) return false;
+        off = fx_mod_total; fx_mod_total += mult * C;
+        fx_mod_srcs.push_back({w, b, mult * C});
+        return true;
+    };
+    auto mk_stream = [&](const std::string& p, const char* s, FluxStreamW& w) {
+        const std::string a = p + "." + s;
+        return add_mod(a + "_mod.lin", 6, w.mod_off) && mk_linear(a + "_attn.qkv", 3 * C, C, true, w.qkv) &&
+               scale_vec(a + "_attn.norm.query_norm.scale", w.qs) && scale_vec(a + "_attn.norm.key_norm.scale", w.ks) &&
+               mk_linear(a + "_attn.proj", C, C, true, w.proj) && mk_linear(a + "_mlp.0", f.mlp_hidden, C, true, w.mlp0) &&
+               mk_linear(a + "_mlp.2", C, f.mlp_hidden, true, w.mlp2);
+    };
+    fx_double.resize(f.depth);
+    for (int i = 0; ok && i < f.depth; ++i) {
+        const std::string p = "double_blocks." + std::to_string(i);
+        ok = mk_stream(p, "img", fx_double[i].img) && mk_stream(p, "txt", fx_double[i].txt);
+    }
+    fx_single.resize(f.depth_single);
+    for (int i = 0; ok && i < f.depth_single; ++i) {
+        const std::string p = "single_blocks." + std::to_string(i);
+        FluxSingleW& s = fx_single[i];
+        ok = add_mod(p + ".modulation.lin", 3, s.mod_off);
+        // linear1 (C -> 3C + mlp) split into its qkv rows and its mlp rows (the mlp half gets the tanh-GELU epilogue)
+        const HostTensor* w1 = ok ? get(p + ".linear1.weight", {3 * C + f.mlp_hidden, C}) : nullptr;
+        const HostTensor* b1 = ok ? get(p + ".linear1.bias", {3 * C + f.mlp_hidden}) : nullptr;
+        ok = ok && w1 && b1;
+        if (ok) {
+            s.lin1_qkv.N = 3 * C; s.lin1_qkv.K = C;
+            s.lin1_qkv.w = upload16((size_t)3 * C, C, [&](size_t r, size_t c) { return w1->at(r * C + c); });
+            s.lin1_qkv.b = upload32((size_t)3 * C, [&](size_t i2) { return b1->at(i2); });
+            s.lin1_mlp.N = f.mlp_hidden; s.lin1_mlp.K = C;
+            s.lin1_mlp.w = upload16((size_t)f.mlp_hidden, C, [&](size_t r, size_t c) { return w1->at((r + 3 * C) * C + c); });
+            s.lin1_mlp.b = upload32((size_t)f.mlp_hidden, [&](size_t i2) { return b1->at(i2 + 3 * C); });
+            ok = s.lin1_qkv.w && s.lin1_qkv.b && s.lin1_mlp.w && s.lin1_mlp.b;
+        }
+        ok = ok && mk_linear(p + ".linear2", C, C + f.mlp_hidden, true, s.lin2) &&
+             scale_vec(p + ".norm.query_norm.scale", s.qs) && scale_vec(p + ".norm.key_norm.scale", s.ks);
+    }
+    ok = ok && add_mod("final_layer.adaLN_modulation.1", 2, fx_final_mod_off) && mk_linear("final_layer.linear", inC, C, true, fx_final);
+    if (ok) {
+        std::vector<size_t> starts; size_t acc = 0;
+        for (auto& s : fx_mod_srcs) { starts.push_back(acc); acc += s.n; }
+        auto find = [&](size_t r) { return (size_t)(std::upper_bound(starts.begin(), starts.end(), r) - starts.begin() - 1); };
+        fx_mod_all.N = fx_mod_total; fx_mod_all.K = C;
+        fx_mod_all.w = upload16(fx_mod_total, C, [&](size_t r, size_t c) { const size_t i = find(r); return fx_mod_srcs[i].w->at((r - starts[i]) * C + c); });
+        fx_mod_all.b = upload32(fx_mod_total, [&](size_t r) { const size_t i = find(r); return fx_mod_srcs[i].b->at(r - starts[i]); });
+        ok = fx_mod_all.w && fx_mod_all.b;
+    }
+    if (!ok) {
+        if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
+        set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
+        return LDX_EHIP;
+    }
+    fx_mod_srcs.clear();
+    host.clear();
+    finalized = true;
+    return LDX_OK;
+}
+
+int Engine::plan_flux(int B, int h, int w, int Lt) {
+    const ldx_flux_config& f = fcfg;
+    const int C = f.hidden_size, H = f.num_heads, D = C / H, MH = f.mlp_hidden;
+    const int Li = (h / 2) * (w / 2), L = Lt + Li, inC = 4 * f.in_channels;
+    for (int pass = 0; pass < 2; ++pass) {
+        ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
+        if (pass == 1) {
+            if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
+            if (!arena) { HIP_OK(hipMalloc(&arena, arena_peak_dry)); arena_cap = arena_peak_dry; }
+        }
+        void* saved = arena;
+        if (pass == 0) arena = nullptr;
+        auto f32buf = [&](size_t n) { const size_t off = a_alloc(n * 4); return (float*)((uintptr_t)arena + off); };
+        fx_temb = f32buf((size_t)B * 256); fx_gemb = f32buf((size_t)B * 256); fx_h1 = f32buf((size_t)B * C);
+        fx_vec = f32buf((size_t)B * C); fx_svec = f32buf((size_t)B * C); fx_mod = f32buf((size_t)B * fx_mod_total);
+        fx_tok = f32buf((size_t)B * Li * inC);
+        auto skinny = [&](const char* name, OpKind kind, const float* x, int ldx_, const LinearW& lw, float* out, int out_act, int accum) {
+            Op o{}; o.kind = kind; o.name = name; o.sk = SkinnyArgs{x, ldx_, lw.w, lw.b, out, lw.N, B, lw.N, lw.K, 0, out_act, accum}; ops.push_back(o);
+            flops += 2.0 * B * (double)lw.N * lw.K;
+        };
+        // vec = time_in(temb(t)) + guidance_in(temb(g)) + vector_in(y)           (Flux.py:683-696)
+        { Op o{}; o.kind = OP_FX_TEMB; o.name = "fx.temb_t"; o.p1 = fx_temb; o.i0 = 0; ops.push_back(o); }
+        skinny("fx.time_in.0", OP_SKINNY, fx_temb, 256, fx_time0, fx_h1, 1, 0);
+        skinny("fx.time_in.1", OP_SKINNY, fx_h1, C, fx_time1, fx_vec, 0, 0);
+        if (f.guidance_embed) {
+            { Op o{}; o.kind = OP_FX_TEMB; o.name = "fx.temb_g"; o.p1 = fx_gemb; o.i0 = 1; ops.push_back(o); }
+            skinny("fx.guidance_in.0", OP_SKINNY, fx_gemb, 256, fx_gd0, fx_h1, 1, 0);
+            skinny("fx.guidance_in.1", OP_SKINNY, fx_h1, C, fx_gd1, fx_vec, 0, 1);
+        }
+        skinny("fx.vector_in.0", OP_FX_SKINNY_Y, nullptr, f.vec_in_dim, fx_vec0, fx_h1, 1, 0);      // x bound per call (y)
+        skinny("fx.vector_in.1", OP_SKINNY, fx_h1, C, fx_vec1, fx_vec, 0, 1);
+        { Op o{}; o.kind = OP_FX_SILU; o.name = "fx.silu_vec"; o.p0 = fx_vec; o.p1 = fx_svec; o.i0 = B * C; ops.push_back(o); }
+        skinny("fx.modulation_all", OP_SKINNY, fx_svec, C, fx_mod_all, fx_mod, 0, 0);
+
+        // joint token buffer and inputs
+        Act X = new_act(B * L, C);
+        Act ptok = new_act(B * Li, inC);
+        { Op o{}; o.kind = OP_FX_PATCH; o.name = "fx.patchify"; o.p1 = ptr(ptok); o.i0 = B; o.i1 = f.in_channels; o.i2 = h; o.i3 = w; ops.push_back(o); }
+        Act ctx16 = new_act(B * Lt, f.context_in_dim);
+        { Op o{}; o.kind = OP_FX_CVT_CTX; o.name = "fx.ctx.cvt"; o.cvt_out = ptr(ctx16); o.cvt_n = (size_t)B * Lt * f.context_in_dim; ops.push_back(o); }
+        auto rows = [&](const Act& t, int r0, int nr) { Act v = t; v.owned = false; v.off = t.off + (size_t)r0 * t.ld * 2; v.rows = nr; return v; };
+        auto img_rows = [&](const Act& t, int b) { return rows(t, b * L + Lt, Li); };
+        auto txt_rows = [&](const Act& t, int b) { return rows(t, b * L, Lt); };
+        for (int b = 0; b < B; ++b) {
+            op_gemm("fx.img_in", rows(ptok, b * Li, Li), fx_img_in, img_rows(X, b), Act{});
+            op_gemm("fx.txt_in", rows(ctx16, b * Lt, Lt), fx_txt_in, txt_rows(X, b), Act{});
+        }
+        release(ptok); release(ctx16);
+
+        auto mod = [&](int off, int which) { return fx_mod + off + (size_t)which * C; };   // which: 0 shift 1 scale 2 gate (+3 for mod2)
+        auto ln_mod = [&](const char* name, Act Xin, Act Y, const float* shift, const float* scale, int rpb) {
+            Op o{}; o.kind = OP_LN; o.name = name;
+            LayerNormArgs& l = o.ln;
+            l.X = ptr(Xin); l.ldx = Xin.ld; l.Y = ptr(Y); l.ldy = Y.ld; l.rows = Xin.rows; l.C = C; l.eps = 1e-6f; l.gamma = nullptr; l.beta = nullptr;
+            l.scale = scale; l.shift = shift; l.mod_ld = fx_mod_total; l.rows_per_batch = rpb;
+            o.bytes = 2.0 * 2.0 * (double)Xin.rows * C; snprintf(o.klabel, sizeof(o.klabel), "ln_kernel");
+            ops.push_back(o);
+        };
+        auto rope = [&](const char* name, Act QKV, const float* qs, const float* ks, int tok0) {
+            Op o{}; o.kind = OP_FX_ROPE; o.name = name;
+            o.rp = QkRopeArgs{ptr(QKV), QKV.ld, QKV.rows, L, H, D, qs, ks, nullptr, nullptr, 1e-6f};
+            o.i0 = tok0;                                 // first token index of this slice in the pe tables
+            ops.push_back(o);
+        };
+        auto gemm_gate = [&](const char* name, Act A, const LinearW& lw, Act Cc, Act R, const float* gate, int rpb, int act) {
+            op_gemm(name, A, lw, Cc, R);
+            GemmArgs& g = ops.back().g;
+            g.gate = gate; g.gate_ld = fx_mod_total; g.rows_per_batch = rpb; g.act = act;
+            if (gate && g.splitk > 1) g.splitk = 1;      // gate/act are not replicated in the split-K reduce path for safety
+        };
+        auto attn = [&](const char* name, Act QKV, Act O) {
+            const char* base = (const char*)ptr(QKV);
+            op_attn(name, base, QKV.ld, base + (size_t)C * 2, QKV.ld, base + (size_t)2 * C * 2, QKV.ld, O, 1, H, QKV.rows, QKV.rows, D);
+        };
+
+        // ---- double-stream blocks ----
+        Act QKV = new_act(B * L, 3 * C), AO = new_act(B * L, C), N1 = new_act(B * L, C), MLP = new_act(B * L, MH);
+        for (const FluxDoubleW& blk : fx_double) {
+            for (int b = 0; b < B; ++b) {
+                const float* mb = nullptr; (void)mb;
+                struct S { const FluxStreamW* w; Act x, n, qkv, ao, mlp; int rows; int tok0; };
+                S st[2] = {{&blk.img, img_rows(X, b), img_rows(N1, b), img_rows(QKV, b), img_rows(AO, b), img_rows(MLP, b), Li, Lt},
+                           {&blk.txt, txt_rows(X, b), txt_rows(N1, b), txt_rows(QKV, b), txt_rows(AO, b), txt_rows(MLP, b), Lt, 0}};
+                for (S& s : st) {
+                    const float* m = fx_mod + (size_t)b * fx_mod_total;
+                    ln_mod("fx.d.norm1", s.x, s.n, m + s.w->mod_off + 0 * C, m + s.w->mod_off + 1 * C, s.rows);
+                    op_gemm("fx.d.qkv", s.n, s.w->qkv, s.qkv, Act{});
+                    rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
+                }
+                attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L));          // joint [txt ; img] sequence
+                for (S& s : st) {
+                    const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
+                    gemm_gate("fx.d.proj", s.ao, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);          // x += gate1 * proj(attn)
+                    ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows);
+                    gemm_gate("fx.d.mlp0", s.n, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2);         // tanh-GELU
+                    gemm_gate("fx.d.mlp2", s.mlp, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);         // x += gate2 * mlp(...)
+                }
+            }
+        }
+        release(MLP);
+        // ---- single-stream blocks on the joint sequence ----
+        Act CAT = new_act(B * L, C + MH);                      // [attn | gelu(mlp)] : linear2's input (torch.cat, Flux.py:413)
+        for (const FluxSingleW& blk : fx_single) {
+            for (int b = 0; b < B; ++b) {
+                const float* m = fx_mod + (size_t)b * fx_mod_total + blk.mod_off;
+                Act xb = rows(X, b * L, L), nb = rows(N1, b * L, L), qb = rows(QKV, b * L, L), cb = rows(CAT, b * L, L);
+                ln_mod("fx.s.pre_norm", xb, nb, m + 0 * C, m + 1 * C, L);
+                op_gemm("fx.s.lin1.qkv", nb, blk.lin1_qkv, qb, Act{});
+                gemm_gate("fx.s.lin1.mlp", nb, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2);
+                rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);
+                attn("fx.s.attn", qb, view(cb, 0, C));
+                gemm_gate("fx.s.lin2", cb, blk.lin2, xb, xb, m + 2 * C, L, 0);                      // x += gate * linear2(cat)
+            }
+        }
+        release(CAT); release(QKV); release(AO);
+        // ---- LastLayer on the img rows ----
+        for (int b = 0; b < B; ++b) {
+            const float* m = fx_mod + (size_t)b * fx_mod_total + fx_final_mod_off;
+            ln_mod("fx.final.norm", img_rows(X, b), img_rows(N1, b), m + 0 * C, m + 1 * C, Li);       // chunk order: shift, scale
+            op_gemm("fx.final.linear", img_rows(N1, b), fx_final, Act{}, Act{});
+            GemmArgs& g = ops.back().g; g.C = nullptr; g.Cf = fx_tok + (size_t)b * Li * inC; g.ldcf = inC;
+        }
+        release(N1); release(X);
+        { Op o{}; o.kind = OP_FX_UNPATCH; o.name = "fx.unpatchify"; o.i0 = B; o.i1 = f.in_channels; o.i2 = h; o.i3 = w; ops.push_back(o); }
+        if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
+    }
+    pB2 = B; ph = h; pw = w; pM = Lt;
+    return LDX_OK;
+}
+
+int Engine::run_flux(const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,
+                     const float* pe_cos, const float* pe_sin, int B, int h, int w, int Lt, bool denoise, float* out, hipStream_t st) {
+    if (!finalized || kind != KIND_FLUX) { set_error("ldx_flux_forward: not a finalized Flux engine"); return LDX_ESTATE; }
+    if (!x || !sigma || !ctx || !y || !pe_cos || !pe_sin || !out || B <= 0 || h <= 0 || w <= 0 || Lt <= 0 || (h & 1) || (w & 1) ||
+        (fcfg.guidance_embed && !guidance)) { set_error("ldx_flux_forward: bad argument (h, w must be even)"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    if (B != pB2 || h != ph || w != pw || Lt != pM) {
+        HIP_OK(hipStreamSynchronize(st));
+        int rc = plan_flux(B, h, w, Lt);
+        if (rc) return rc;
+    }
+    b_x = x; b_s = sigma; b_ctx = ctx; b_y = y; b_guid = guidance; b_cos = pe_cos; b_sin = pe_sin; b_out = out; b_den = denoise;
+    prof_graph = false;
+    int rc = exec_ops(st);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+}  // namespace ldx

@@ -217,6 +217,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const int m = m0 + wm * (BM / 2) + i * 16 + l15;
         if (m >= p.M) continue;
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
         if (BN != 128 || BM != 128 || !p.geglu) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -230,7 +231,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     if (p.act == 1) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
                     }
+                    if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
                     if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
                     if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -240,6 +245,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                         if (p.bias) x += p.bias[n + r];
                         if (rv) x += rv[n + r];
                         if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+                        else if (p.act == 2) x = gelu_tanh_f(x);
+                        if (gt) x *= gt[n + r];
                         if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
                         if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
                         if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
@@ -294,6 +301,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             if (p.bias) x += p.bias[n + r];
             if (rv) x += rv[n + r];
             if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+            else if (p.act == 2) x = gelu_tanh_f(x);
+            if (p.gate) x *= p.gate[(long)(m / p.rows_per_batch) * p.gate_ld + n + r];
             if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
             v[r] = x;
         }
@@ -403,6 +412,7 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
             if (lane == 0 && m < p.M) {
                 float o = v + (p.bias ? p.bias[n] : 0.f);
                 if (p.out_act) o = o / (1.0f + expf(-o));
+                if (p.accum) o += p.out[(long)m * p.ldo + n];
                 p.out[(long)m * p.ldo + n] = o;
             }
         }

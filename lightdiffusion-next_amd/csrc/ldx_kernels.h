@@ -33,7 +33,9 @@ struct GemmArgs {
     const float* bias;             // [N] or null
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
     int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2
-    int act;                       // 0 none, 1 quick-GELU x*sigmoid(1.702x) after bias (CLIP MLP, clip/Clip.py:74-77)
+    int act;                       // 0 none, 1 quick-GELU x*sigmoid(1.702x) after bias (CLIP MLP, clip/Clip.py:74-77),
+                                   // 2 tanh-GELU (Flux MLPs, BlackForest/Flux.py:279,388)
+    const float* gate; int gate_ld; // per-batch channel gate (Flux adaLN): v *= gate[(m / rows_per_batch)][n] before + R
     const void* R; int ldr;        // residual (16-bit) or null
     void* C; int ldc;              // 16-bit output or null
     float* Cf; int ldcf;           // fp32 output or null
@@ -49,6 +51,7 @@ int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
 struct SkinnyArgs {
     const float* x; int ldx; const void* W; const float* bias; float* out; int ldo;
     int M, N, K; int in_act; int out_act;
+    int accum;                     // 1: out += result (sums the Flux time / guidance / vector embedders)
 };
 void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s);
 
@@ -76,9 +79,12 @@ constexpr int GN_NCHUNK = 256;
 void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s);
 
 // LayerNorm over the last dim C of [rows][ldx] -> [rows][ldy]
+// gamma/beta may be null (elementwise_affine=False); optional adaLN modulation (Flux):
+// y = (1 + scale[b][c]) * y + shift[b][c] with b = row / rows_per_batch.  C <= 3072.
 struct LayerNormArgs {
     const void* X; int ldx; void* Y; int ldy; int rows, C; float eps;
     const float* gamma; const float* beta;
+    const float* scale; const float* shift; int mod_ld; int rows_per_batch;
 };
 void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s);
 
@@ -113,6 +119,22 @@ void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s);
 void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType dt, hipStream_t s);
 // CLIP embeddings (clip/Clip.py:254-294): x[b][t][:] = tok[id[b][t]][:] + pos[t][:]  (fp32 tables -> 16-bit)
 void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int T, int C, int vocab, DType dt, hipStream_t s);
+
+// Flux: per-head RMSNorm of q and k (QKNorm, BlackForest/Flux.py:148-200, eps 1e-6) followed by RoPE
+// (apply_rope :73-82) in place on a fused [rows][ld] q|k|v buffer (q at column 0, k at column C = H*D).
+// cos/sin: [L][D/2] fp32 tables built by the host exactly as rope() does (:36-70); token = row % L.
+struct QkRopeArgs {
+    void* QKV; int ld; int rows; int L; int H, D; const float* qscale; const float* kscale;
+    const float* cosT; const float* sinT; float eps;
+};
+void launch_qk_norm_rope(const QkRopeArgs& a, DType dt, hipStream_t s);
+// timestep_embedding_flux (sample/sampling_util.py:78-104): out[b][:] = [cos(1000 t f_j) | sin(1000 t f_j)], dim 256
+void launch_flux_temb(const float* t, float* out, int B, int dim, float factor, hipStream_t s);
+void launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s);
+// patchify  x[B][C][H][W] fp32 -> tokens [B*(H/2)*(W/2)][4C] 16-bit, column = c*4 + ph*2 + pw   (Flux3.forward :742-748)
+void launch_flux_patchify(const float* x, void* out, int B, int C, int H, int W, DType dt, hipStream_t s);
+// unpatchify + CONST.calculate_denoised (sampling.py:108-122): out = x - tok*sigma (or tok if x == null), fp32 NCHW
+void launch_flux_unpatchify(const float* tok, int ld, const float* x, const float* sigma, float* out, int B, int C, int H, int W, hipStream_t s);
 
 // Sampler elementwise kernels (fp32, reference samplers.py / CFG.py):
 //  d = lerp(den_uncond, den_cond, cfg)                             (torch.lerp, CFG.py:60)

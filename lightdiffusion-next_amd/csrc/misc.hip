@@ -232,6 +232,56 @@ void launch_clip_embed(const int* ids, const float* tok, const float* pos, void*
     else hipLaunchKernelGGL((clip_embed_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (_Float16*)out, B, Tn, C, vocab);
 }
 
+__global__ __launch_bounds__(256) void flux_temb_kernel(const float* t, float* out, int B, int dim, float factor) {
+    const int half = dim / 2;
+    for (int idx = blockIdx.x * 256 + threadIdx.x; idx < B * half; idx += gridDim.x * 256) {
+        const int b = idx / half, j = idx % half;
+        const float freq = expf(-9.210340371976184f * (float)j / (float)half);      // exp(-ln(10000) j / half)
+        const float a = (factor * t[b]) * freq;
+        out[(long)b * dim + j] = cosf(a);
+        out[(long)b * dim + half + j] = sinf(a);
+    }
+}
+void launch_flux_temb(const float* t, float* out, int B, int dim, float factor, hipStream_t s) {
+    hipLaunchKernelGGL(flux_temb_kernel, dim3(grid_for((size_t)B * dim / 2)), dim3(256), 0, s, t, out, B, dim, factor);
+}
+__global__ __launch_bounds__(256) void silu_f32_kernel(const float* in, float* out, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) { const float x = in[i]; out[i] = x / (1.0f + expf(-x)); }
+}
+void launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s) {
+    hipLaunchKernelGGL(silu_f32_kernel, dim3(grid_for(n)), dim3(256), 0, s, in, out, n);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void flux_patchify_kernel(const float* x, T* out, int B, int C, int H, int W) {
+    const int h2 = H / 2, w2 = W / 2, K = 4 * C;
+    const long total = (long)B * h2 * w2 * K;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int col = (int)(idx % K);
+        const long tokb = idx / K;
+        const int tw = (int)(tokb % w2), th = (int)((tokb / w2) % h2), b = (int)(tokb / ((long)w2 * h2));
+        const int c = col >> 2, ph = (col >> 1) & 1, pw = col & 1;
+        out[idx] = (T)x[(((long)b * C + c) * H + th * 2 + ph) * W + tw * 2 + pw];
+    }
+}
+void launch_flux_patchify(const float* x, void* out, int B, int C, int H, int W, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * (H / 2) * (W / 2) * 4 * C;
+    if (dt == DT_BF16) hipLaunchKernelGGL((flux_patchify_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, x, (__bf16*)out, B, C, H, W);
+    else hipLaunchKernelGGL((flux_patchify_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, x, (_Float16*)out, B, C, H, W);
+}
+__global__ __launch_bounds__(256) void flux_unpatchify_kernel(const float* tok, int ld, const float* x, const float* sigma, float* out, int B, int C, int H, int W) {
+    const int h2 = H / 2, w2 = W / 2;
+    const long total = (long)B * C * H * W;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int xw = (int)(idx % W), yh = (int)((idx / W) % H), c = (int)((idx / ((long)W * H)) % C), b = (int)(idx / ((long)W * H * C));
+        const long t = ((long)b * h2 + (yh >> 1)) * w2 + (xw >> 1);
+        const float v = tok[t * ld + c * 4 + (yh & 1) * 2 + (xw & 1)];
+        out[idx] = x ? (x[idx] - v * sigma[b]) : v;
+    }
+}
+void launch_flux_unpatchify(const float* tok, int ld, const float* x, const float* sigma, float* out, int B, int C, int H, int W, hipStream_t s) {
+    hipLaunchKernelGGL(flux_unpatchify_kernel, dim3(grid_for((size_t)B * C * H * W)), dim3(256), 0, s, tok, ld, x, sigma, out, B, C, H, W);
+}
+
 #pragma clang fp contract(off)
 __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs p) {
     // Same operation order (and no FMA contraction) as the reference's fp32 tensor expressions.

@@ -172,8 +172,9 @@ void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, row held in registers (C <= 2048), two-pass mean / variance.
-template <typename T>
+// LayerNorm: one wave per row, row held in registers (C <= 512 * NCH), two-pass mean / variance.
+// Optional affine (gamma/beta) and optional per-batch adaLN modulation (Flux).
+template <typename T, int NCH>
 __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
     const int lane = threadIdx.x & 63;
     const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -181,10 +182,10 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
     const int nch = p.C >> 3;
     const T* __restrict__ x = (const T*)p.X + row * p.ldx;
     T* __restrict__ y = (T*)p.Y + row * p.ldy;
-    float f[4][8];
+    float f[NCH][8];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
             unpack8<T>(*(const uint4*)(x + ch * 8), f[i]);
@@ -195,7 +196,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
     const float mean = wave_sum(sum) / (float)p.C;
     float vs = 0.f;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
 #pragma unroll
@@ -203,17 +204,20 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
         }
     }
     const float rstd = rsqrtf(wave_sum(vs) / (float)p.C + p.eps);
+    const long mb = p.scale ? (row / p.rows_per_batch) * (long)p.mod_ld : 0;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NCH; ++i) {
         const int ch = lane + 64 * i;
         if (ch < nch) {
             float o[8];
-            const float4 g0 = *(const float4*)(p.gamma + ch * 8), g1 = *(const float4*)(p.gamma + ch * 8 + 4);
-            const float4 b0 = *(const float4*)(p.beta + ch * 8), b1 = *(const float4*)(p.beta + ch * 8 + 4);
-            const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
 #pragma unroll
-            for (int e = 0; e < 8; ++e) o[e] = (f[i][e] - mean) * rstd * gg[e] + bb[e];
+            for (int e = 0; e < 8; ++e) {
+                const int c = ch * 8 + e;
+                float v = (f[i][e] - mean) * rstd;
+                if (p.gamma) v = v * p.gamma[c] + p.beta[c];
+                if (p.scale) v = (1.0f + p.scale[mb + c]) * v + p.shift[mb + c];
+                o[e] = v;
+            }
             *(uint4*)(y + ch * 8) = pack8<T>(o);
         }
     }
@@ -222,8 +226,46 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
 void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s) {
     if (a.rows <= 0) return;
     dim3 grid((a.rows + 3) / 4), block(256);
-    if (dt == DT_BF16) hipLaunchKernelGGL((ln_kernel<__bf16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((ln_kernel<_Float16>), grid, block, 0, s, a);
+    const bool big = a.C > 2048;
+    if (dt == DT_BF16) { if (big) hipLaunchKernelGGL((ln_kernel<__bf16, 6>), grid, block, 0, s, a); else hipLaunchKernelGGL((ln_kernel<__bf16, 4>), grid, block, 0, s, a); }
+    else { if (big) hipLaunchKernelGGL((ln_kernel<_Float16, 6>), grid, block, 0, s, a); else hipLaunchKernelGGL((ln_kernel<_Float16, 4>), grid, block, 0, s, a); }
+}
+
+// ------------------------------------------------------------------------------------------
+// Flux q/k: per-head RMSNorm + rotary embedding, in place.  One thread per (row, q|k, head, pair).
+template <typename T>
+__global__ __launch_bounds__(256) void qk_norm_rope_kernel(const QkRopeArgs p) {
+    const int hp = p.D >> 1;                                   // pairs per head (power of two <= 64)
+    const long total = (long)p.rows * 2 * p.H * hp;
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const bool live = idx < total;
+    const long i = live ? idx : total - 1;
+    const int pr = (int)(i % hp);
+    long r = i / hp;
+    const int h = (int)(r % p.H); r /= p.H;
+    const int which = (int)(r & 1);                            // 0 = q, 1 = k
+    const long row = r >> 1;
+    T* __restrict__ ptr = (T*)p.QKV + row * p.ld + which * (p.H * p.D) + h * p.D + pr * 2;
+    const unsigned int raw = *(const unsigned int*)ptr;
+    union { unsigned int u; T t[2]; } in; in.u = raw;
+    const float x0 = (float)in.t[0], x1 = (float)in.t[1];
+    float ss = x0 * x0 + x1 * x1;
+    for (int o = hp >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    const float rr = rsqrtf(ss / (float)p.D + p.eps);
+    const float* sc = which ? p.kscale : p.qscale;
+    const float a = x0 * rr * sc[pr * 2], b = x1 * rr * sc[pr * 2 + 1];
+    const int tok = (int)(row % p.L);
+    const float cs = p.cosT[(long)tok * hp + pr], sn = p.sinT[(long)tok * hp + pr];
+    union { unsigned int u; T t[2]; } out;
+    out.t[0] = (T)(cs * a - sn * b);
+    out.t[1] = (T)(sn * a + cs * b);
+    if (live) *(unsigned int*)ptr = out.u;
+}
+void launch_qk_norm_rope(const QkRopeArgs& a, DType dt, hipStream_t s) {
+    const long total = (long)a.rows * 2 * a.H * (a.D / 2);
+    dim3 grid((unsigned)((total + 255) / 256)), block(256);
+    if (dt == DT_BF16) hipLaunchKernelGGL((qk_norm_rope_kernel<__bf16>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((qk_norm_rope_kernel<_Float16>), grid, block, 0, s, a);
 }
 
 }  // namespace ldx

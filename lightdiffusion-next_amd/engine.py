@@ -10,7 +10,7 @@ import math
 import torch
 
 from . import lib
-from .weights import UNetConfig, VAEConfig, CLIPConfig
+from .weights import UNetConfig, VAEConfig, CLIPConfig, FluxConfig
 
 
 def sd15_sigmas():
@@ -228,5 +228,71 @@ class CLIPTextEngine:
         cond = out[-1:] if not output else torch.cat(output, dim=-2)
         return cond, pooled[0:1].float().cpu()
 
+    close = UNetEngine.close
+    __del__ = UNetEngine.__del__
+
+
+def flux_rope_tables(cfg: FluxConfig, batch_txt_len: int, h: int, w: int):
+    """pe for ids = [txt_ids (zeros) ; img_ids] exactly as Flux3.forward + EmbedND + rope() build it
+    (src/BlackForest/Flux.py:36-70, 96-103, 750-771): returns (cos, sin) fp32 [Lt + (h/2)(w/2)][head_dim/2]."""
+    h_len, w_len = (h + 1) // 2, (w + 1) // 2
+    img_ids = torch.zeros((h_len, w_len, 3), dtype=torch.float32)
+    img_ids[..., 1] = img_ids[..., 1] + torch.linspace(0, h_len - 1, steps=h_len, dtype=torch.float32)[:, None]
+    img_ids[..., 2] = img_ids[..., 2] + torch.linspace(0, w_len - 1, steps=w_len, dtype=torch.float32)[None, :]
+    ids = torch.cat([torch.zeros((batch_txt_len, 3), dtype=torch.float32), img_ids.reshape(-1, 3)], dim=0)
+    cos, sin = [], []
+    for i, dim in enumerate(cfg.axes_dim):
+        scale = torch.linspace(0, (dim - 2) / dim, steps=dim // 2, dtype=torch.float64)
+        omega = 1.0 / (cfg.theta ** scale)
+        out = torch.einsum("n,d->nd", ids[:, i].to(torch.float32), omega)          # float32 x float64 -> float64, as rope()
+        cos.append(torch.cos(out).to(torch.float32)); sin.append(torch.sin(out).to(torch.float32))
+    return torch.cat(cos, dim=-1).contiguous(), torch.cat(sin, dim=-1).contiguous()
+
+
+class FluxEngine:
+    """Flux3.forward behind BaseModel.apply_model with CONST prediction."""
+
+    def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16"):
+        self._lib = lib.load()
+        self._h = C.c_void_p()
+        self.cfg, self.device = cfg, torch.device("cuda", device)
+        c = lib.ldx_flux_config()
+        c.compute_dtype = {"bf16": lib.LDX_BF16, "f16": lib.LDX_F16, "fp16": lib.LDX_F16}[dtype]
+        c.in_channels, c.vec_in_dim, c.context_in_dim = cfg.in_channels, cfg.vec_in_dim, cfg.context_in_dim
+        c.hidden_size, c.mlp_hidden, c.num_heads = cfg.hidden_size, cfg.mlp_hidden, cfg.num_heads
+        c.depth, c.depth_single, c.guidance_embed = cfg.depth, cfg.depth_single_blocks, int(cfg.guidance_embed)
+        lib.check(self._lib.ldx_flux_create(C.byref(c), device, C.byref(self._h)), "ldx_flux_create")
+        _load_state_dict(self._lib, self._h, state_dict, strip=("model.diffusion_model.",))
+        lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+        self._pe = {}
+
+    def _run(self, x, sigma, ctx, y, guidance, denoise):
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+        b, _, h, w = x.shape
+        lt = ctx.shape[1]
+        key = (lt, h, w)
+        if key not in self._pe:
+            cos, sin = flux_rope_tables(self.cfg, lt, h, w)
+            self._pe[key] = (cos.to(self.device), sin.to(self.device))
+        cos, sin = self._pe[key]
+        f32 = lambda t: None if t is None else t.to(self.device, torch.float32).contiguous()
+        x, sigma, ctx, y, guidance = f32(x), f32(sigma), f32(ctx), f32(y), f32(guidance)
+        out = torch.empty_like(x)
+        lib.check(self._lib.ldx_flux_forward(self._h, lib.ptr(x), lib.ptr(sigma), lib.ptr(ctx), lib.ptr(y), lib.ptr(guidance),
+                                             lib.ptr(cos), lib.ptr(sin), b, h, w, lt, int(denoise), lib.ptr(out),
+                                             lib.current_stream_ptr()), "ldx_flux_forward")
+        return out
+
+    def forward(self, x, timestep, ctx, y, guidance):
+        """Flux3.forward(x, timestep, context, y, guidance) (Flux.py:732-778)."""
+        return self._run(x, timestep, ctx, y, guidance, False)
+
+    def denoise(self, x, sigma, ctx, y, guidance):
+        """BaseModel.apply_model for ModelType.FLUX: x - Flux3(x, sigma, ...) * sigma (sampling.py:100-155)."""
+        return self._run(x, sigma, ctx, y, guidance, True)
+
+    profile = UNetEngine.profile
+    profile_report = UNetEngine.profile_report
+    plan_info = UNetEngine.plan_info
     close = UNetEngine.close
     __del__ = UNetEngine.__del__

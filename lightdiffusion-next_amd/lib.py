@@ -43,6 +43,12 @@ class ldx_clip_config(C.Structure):
                 ("intermediate_size", C.c_int32), ("max_positions", C.c_int32), ("vocab_size", C.c_int32)]
 
 
+class ldx_flux_config(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("in_channels", C.c_int32), ("vec_in_dim", C.c_int32), ("context_in_dim", C.c_int32),
+                ("hidden_size", C.c_int32), ("mlp_hidden", C.c_int32), ("num_heads", C.c_int32), ("depth", C.c_int32),
+                ("depth_single", C.c_int32), ("guidance_embed", C.c_int32)]
+
+
 _vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
 _SIGS = {
     "ldx_version": (C.c_char_p, []),
@@ -62,6 +68,8 @@ _SIGS = {
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldx_flux_create": (_i, [C.POINTER(ldx_flux_config), _i, C.POINTER(_vp)]),
+    "ldx_flux_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldx_sampler_step": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
     "ldx_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ldx_op_convert": (_i, [_vp, _vp, _i64, _i, _i, _vp]),

@@ -142,6 +142,9 @@ def _is_norm_weight(key: str) -> bool:
             or name.endswith("final_layer_norm") or ("norm" in parts[-2]))
 
 
+_is_norm_weight_base = _is_norm_weight
+
+
 def synth_tensor(key: str, shape, seed: int, dtype=torch.float16) -> torch.Tensor:
     """Deterministic per-key fill (independent of iteration order): biases ~N(0,.02), norm scales
     1+N(0,.02), everything else N(0, 1/fan_in) — variance-preserving so activations stay O(1)."""
@@ -150,7 +153,7 @@ def synth_tensor(key: str, shape, seed: int, dtype=torch.float16) -> torch.Tenso
     n = torch.randn(tuple(shape), generator=g, dtype=torch.float32)
     if key.endswith(".bias"):
         t = 0.02 * n
-    elif _is_norm_weight(key):
+    elif _is_norm_weight(key) or key.endswith("_norm.scale"):
         t = 1.0 + 0.02 * n
     else:
         fan_in = 1
@@ -259,4 +262,73 @@ def clip_state_dict_spec(cfg: CLIPConfig):
                  (f"{p}.mlp.fc2.weight", (e, f)), (f"{p}.mlp.fc2.bias", (e,))]
     spec += [("final_layer_norm.weight", (e,)), ("final_layer_norm.bias", (e,))]
     spec += [("text_projection.weight", (e, e))]       # CLIPTextModel.text_projection (CLIPTextModel.py:126-128), no prefix
+    return spec
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class FluxConfig:
+    """FluxParams (src/BlackForest/Flux.py:293-306); defaults = flux-dev."""
+
+    in_channels: int = 16
+    vec_in_dim: int = 768
+    context_in_dim: int = 4096
+    hidden_size: int = 3072
+    mlp_ratio: float = 4.0
+    num_heads: int = 24
+    depth: int = 19
+    depth_single_blocks: int = 38
+    axes_dim: Tuple[int, ...] = (16, 56, 56)
+    theta: int = 10000
+    qkv_bias: bool = True
+    guidance_embed: bool = True
+
+    @property
+    def mlp_hidden(self) -> int:
+        return int(self.hidden_size * self.mlp_ratio)
+
+    @staticmethod
+    def tiny() -> "FluxConfig":
+        """SURVEY Appendix B tiny Flux3, widened to the engine's multiples (hidden 64, 2 heads of 32)."""
+        return FluxConfig(in_channels=16, vec_in_dim=32, context_in_dim=48, hidden_size=64, num_heads=2, depth=2,
+                          depth_single_blocks=3, axes_dim=(8, 12, 12))
+
+    def reference_kwargs(self) -> dict:
+        return dict(in_channels=self.in_channels, vec_in_dim=self.vec_in_dim, context_in_dim=self.context_in_dim,
+                    hidden_size=self.hidden_size, mlp_ratio=self.mlp_ratio, num_heads=self.num_heads, depth=self.depth,
+                    depth_single_blocks=self.depth_single_blocks, axes_dim=list(self.axes_dim), theta=self.theta,
+                    qkv_bias=self.qkv_bias, guidance_embed=self.guidance_embed)
+
+
+def flux_state_dict_spec(cfg: FluxConfig):
+    """Flux3 state-dict keys in module creation order (Flux.py:543-657)."""
+    c, m, d = cfg.hidden_size, cfg.mlp_hidden, cfg.hidden_size // cfg.num_heads
+    inc = 4 * cfg.in_channels
+    spec = []
+
+    def lin(name, n, k, bias=True):
+        nonlocal spec
+        spec += [(f"{name}.weight", (n, k))] + ([(f"{name}.bias", (n,))] if bias else [])
+
+    lin("img_in", c, inc)
+    lin("time_in.in_layer", c, 256); lin("time_in.out_layer", c, c)
+    lin("vector_in.in_layer", c, cfg.vec_in_dim); lin("vector_in.out_layer", c, c)
+    if cfg.guidance_embed:
+        lin("guidance_in.in_layer", c, 256); lin("guidance_in.out_layer", c, c)
+    lin("txt_in", c, cfg.context_in_dim)
+    for i in range(cfg.depth):
+        p = f"double_blocks.{i}"
+        for s in ("img", "txt"):
+            lin(f"{p}.{s}_mod.lin", 6 * c, c)
+            lin(f"{p}.{s}_attn.qkv", 3 * c, c, cfg.qkv_bias)
+            spec += [(f"{p}.{s}_attn.norm.query_norm.scale", (d,)), (f"{p}.{s}_attn.norm.key_norm.scale", (d,))]
+            lin(f"{p}.{s}_attn.proj", c, c)
+            lin(f"{p}.{s}_mlp.0", m, c); lin(f"{p}.{s}_mlp.2", c, m)
+    for i in range(cfg.depth_single_blocks):
+        p = f"single_blocks.{i}"
+        lin(f"{p}.linear1", 3 * c + m, c); lin(f"{p}.linear2", c, c + m)
+        spec += [(f"{p}.norm.query_norm.scale", (d,)), (f"{p}.norm.key_norm.scale", (d,))]
+        lin(f"{p}.modulation.lin", 3 * c, c)
+    lin("final_layer.linear", inc, c)
+    lin("final_layer.adaLN_modulation.1", 2 * c, c)
     return spec

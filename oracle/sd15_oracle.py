@@ -491,3 +491,103 @@ def clip_encode_token_weights(sd, cfg, token_weight_pairs, layer_idx=-2, special
         output.append(z)
     cond = out[-1:] if not output else torch.cat(output, dim=-2)
     return cond, pooled[0:1]
+
+
+# ---------------------------------------------------------------------------------------------------
+# Flux DiT  (src/BlackForest/Flux.py)
+def flux_rope(pos, dim, theta):
+    """rope() (Flux.py:36-70): [..., n] -> [..., n, dim/2, 2, 2] rotation matrices, fp64 frequencies."""
+    scale = torch.linspace(0, (dim - 2) / dim, steps=dim // 2, dtype=torch.float64)
+    omega = 1.0 / (theta ** scale)
+    out = torch.einsum("...n,d->...nd", pos.to(dtype=torch.float32), omega)
+    out = torch.stack([torch.cos(out), -torch.sin(out), torch.sin(out), torch.cos(out)], dim=-1)
+    return out.reshape(*out.shape[:-1], 2, 2).to(torch.float32)
+
+
+def flux_apply_rope(xq, xk, freqs_cis):
+    """apply_rope (Flux.py:73-82)."""
+    xq_ = xq.float().reshape(*xq.shape[:-1], -1, 1, 2)
+    xk_ = xk.float().reshape(*xk.shape[:-1], -1, 1, 2)
+    xq_out = freqs_cis[..., 0] * xq_[..., 0] + freqs_cis[..., 1] * xq_[..., 1]
+    xk_out = freqs_cis[..., 0] * xk_[..., 0] + freqs_cis[..., 1] * xk_[..., 1]
+    return xq_out.reshape(*xq.shape), xk_out.reshape(*xk.shape)
+
+
+def flux_temb(t, dim=256, max_period=10000, time_factor=1000.0):
+    """timestep_embedding_flux (sample/sampling_util.py:78-104)."""
+    t = time_factor * t
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+def _rms(x, scale):
+    return F.rms_norm(x, scale.shape, weight=scale, eps=1e-6)                                  # rms_norm (Flux.py:502-524)
+
+
+def _flux_attn(q, k, v, pe):
+    """attention() (Flux.py:18-33): rope then SDPA over [B,H,L,D], back to [B,L,H*D]."""
+    q, k = flux_apply_rope(q, k, pe)
+    o = F.scaled_dot_product_attention(q, k, v)
+    return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
+
+
+def flux_forward(sd, cfg, x, timestep, context, y, guidance):
+    """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output."""
+    w = W(sd)
+    lin = lambda name, t: F.linear(t, w(name + ".weight"), w(name + ".bias") if w.has(name + ".bias") else None)
+    mlp_emb = lambda name, t: lin(name + ".out_layer", F.silu(lin(name + ".in_layer", t)))
+    bs, c, h, wd = x.shape
+    hl, wl = h // 2, wd // 2
+    img = x.reshape(bs, c, hl, 2, wl, 2).permute(0, 2, 4, 1, 3, 5).reshape(bs, hl * wl, c * 4)    # b (h w) (c ph pw)
+    img_ids = torch.zeros((hl, wl, 3))
+    img_ids[..., 1] += torch.linspace(0, hl - 1, steps=hl)[:, None]
+    img_ids[..., 2] += torch.linspace(0, wl - 1, steps=wl)[None, :]
+    img_ids = img_ids.reshape(1, hl * wl, 3).expand(bs, -1, -1)
+    txt_ids = torch.zeros((bs, context.shape[1], 3))
+    ids = torch.cat((txt_ids, img_ids), dim=1)
+    pe = torch.cat([flux_rope(ids[..., i], cfg.axes_dim[i], cfg.theta) for i in range(3)], dim=-3).unsqueeze(1)
+    img = lin("img_in", img)
+    vec = mlp_emb("time_in", flux_temb(timestep))
+    if cfg.guidance_embed:
+        vec = vec + mlp_emb("guidance_in", flux_temb(guidance))
+    vec = vec + mlp_emb("vector_in", y)
+    txt = lin("txt_in", context)
+    C, H = cfg.hidden_size, cfg.num_heads
+    ln = lambda t: F.layer_norm(t, (C,), eps=1e-6)
+    heads = lambda t: t.view(t.shape[0], t.shape[1], 3, H, -1).permute(2, 0, 3, 1, 4)
+    lt = txt.shape[1]
+    for i in range(cfg.depth):                                                                 # DoubleStreamBlock.forward :298-348
+        p = f"double_blocks.{i}."
+        im = lin(p + "img_mod.lin", F.silu(vec))[:, None, :].chunk(6, dim=-1)
+        tm = lin(p + "txt_mod.lin", F.silu(vec))[:, None, :].chunk(6, dim=-1)
+        iq, ik, iv = heads(lin(p + "img_attn.qkv", (1 + im[1]) * ln(img) + im[0]))
+        iq, ik = _rms(iq, w(p + "img_attn.norm.query_norm.scale")), _rms(ik, w(p + "img_attn.norm.key_norm.scale"))
+        tq, tk, tv = heads(lin(p + "txt_attn.qkv", (1 + tm[1]) * ln(txt) + tm[0]))
+        tq, tk = _rms(tq, w(p + "txt_attn.norm.query_norm.scale")), _rms(tk, w(p + "txt_attn.norm.key_norm.scale"))
+        attn = _flux_attn(torch.cat((tq, iq), 2), torch.cat((tk, ik), 2), torch.cat((tv, iv), 2), pe)
+        ta, ia = attn[:, :lt], attn[:, lt:]
+        img = img + im[2] * lin(p + "img_attn.proj", ia)
+        img = img + im[5] * lin(p + "img_mlp.2", F.gelu(lin(p + "img_mlp.0", (1 + im[4]) * ln(img) + im[3]), approximate="tanh"))
+        txt = txt + tm[2] * lin(p + "txt_attn.proj", ta)
+        txt = txt + tm[5] * lin(p + "txt_mlp.2", F.gelu(lin(p + "txt_mlp.0", (1 + tm[4]) * ln(txt) + tm[3]), approximate="tanh"))
+    xj = torch.cat((txt, img), 1)
+    for i in range(cfg.depth_single_blocks):                                                   # SingleStreamBlock.forward :389-418
+        p = f"single_blocks.{i}."
+        shift, scale, gate = lin(p + "modulation.lin", F.silu(vec))[:, None, :].chunk(3, dim=-1)
+        qkv, mlp = torch.split(lin(p + "linear1", (1 + scale) * ln(xj) + shift), [3 * C, cfg.mlp_hidden], dim=-1)
+        q, k, v = heads(qkv)
+        q, k = _rms(q, w(p + "norm.query_norm.scale")), _rms(k, w(p + "norm.key_norm.scale"))
+        attn = _flux_attn(q, k, v, pe)
+        xj = xj + gate * lin(p + "linear2", torch.cat((attn, F.gelu(mlp, approximate="tanh")), 2))
+    img = xj[:, lt:]
+    shift, scale = lin("final_layer.adaLN_modulation.1", F.silu(vec)).chunk(2, dim=1)           # LastLayer.forward :455-471
+    img = lin("final_layer.linear", (1 + scale[:, None, :]) * ln(img) + shift[:, None, :])
+    return img.reshape(bs, hl, wl, c, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(bs, c, h, wd)
+
+
+def flux_apply_model(sd, cfg, x, sigma, context, y, guidance):
+    """BaseModel.apply_model with CONST (sampling.py:100-155): input unscaled, t = sigma, denoised = x - out*sigma."""
+    out = flux_forward(sd, cfg, x, sigma, context, y, guidance)
+    return x - out * sigma.view(-1, 1, 1, 1)
