@@ -379,51 +379,78 @@ void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Skinny GEMM (M <= 64): one wave per output column n, lanes stride K in 8-element chunks.
+// Skinny GEMM (tiny M): HBM-bound on the weight matrix.  One workgroup = 4 waves x 4 output columns each; the
+// (<= 4 row) activation block is staged once in LDS as fp32, and every wave keeps 4 independent 16-byte weight
+// streams in flight so the loads pipeline.
 template <typename T>
 __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
-    const int lane = threadIdx.x & 63;
-    const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (n >= p.N) return;
-    const T* __restrict__ w = (const T*)p.W + (long)n * p.K;
+    extern __shared__ float sx[];                          // [mrows][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int n0 = (blockIdx.x * 4 + wave) * 4;
     for (int mb = 0; mb < p.M; mb += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        const int mr = min(4, p.M - mb);
+        __syncthreads();
+        for (int i = threadIdx.x; i < mr * p.K; i += 256) {
+            float xv = p.x[(long)(mb + i / p.K) * p.ldx + (i % p.K)];
+            if (p.in_act) xv = xv / (1.0f + expf(-xv));
+            sx[i] = xv;
+        }
+        __syncthreads();
+        if (n0 >= p.N) continue;
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[r][mi] = 0.f;
+        const T* __restrict__ w = (const T*)p.W;
         for (int k = lane * 8; k < p.K; k += 64 * 8) {
-            float wf[8];
-            unpack8<T>(*(const uint4*)(w + k), wf);
+            uint4 wv[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) wv[r] = (n0 + r < p.N) ? *(const uint4*)(w + (long)(n0 + r) * p.K + k) : make_uint4(0, 0, 0, 0);
+            float xr[4][8];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) xr[mi][e] = mi < mr ? sx[mi * p.K + k + e] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float wf[8];
+                unpack8<T>(wv[r], wf);
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[r][mi] = fmaf(xr[mi][e], wf[e], acc[r][mi]);
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi) {
-                const int m = mb + mi;
-                if (m < p.M) {
-                    const float* xr = p.x + (long)m * p.ldx + k;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) {
-                        float xv = xr[e];
-                        if (p.in_act) xv = xv / (1.0f + expf(-xv));
-                        acc[mi] = fmaf(xv, wf[e], acc[mi]);
-                    }
+                const float v = wave_sum(acc[r][mi]);
+                const int m = mb + mi, n = n0 + r;
+                if (lane == 0 && mi < mr && n < p.N) {
+                    float o = v + (p.bias ? p.bias[n] : 0.f);
+                    if (p.out_act) o = o / (1.0f + expf(-o));
+                    if (p.accum) o += p.out[(long)m * p.ldo + n];
+                    p.out[(long)m * p.ldo + n] = o;
                 }
             }
-        }
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi) {
-            const float v = wave_sum(acc[mi]);
-            const int m = mb + mi;
-            if (lane == 0 && m < p.M) {
-                float o = v + (p.bias ? p.bias[n] : 0.f);
-                if (p.out_act) o = o / (1.0f + expf(-o));
-                if (p.accum) o += p.out[(long)m * p.ldo + n];
-                p.out[(long)m * p.ldo + n] = o;
-            }
-        }
     }
 }
 
 void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
-    dim3 grid((a.N + 3) / 4), block(256);
-    if (dt == DT_BF16) hipLaunchKernelGGL((skinny_kernel<__bf16>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((skinny_kernel<_Float16>), grid, block, 0, s, a);
+    dim3 grid((a.N + 15) / 16), block(256);
+    const size_t lds = (size_t)4 * a.K * sizeof(float);
+    if (dt == DT_BF16) {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL((skinny_kernel<__bf16>), grid, block, lds, s, a);
+    } else {
+        static bool attr = false;
+        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        hipLaunchKernelGGL((skinny_kernel<_Float16>), grid, block, lds, s, a);
+    }
 }
 
 }  // namespace ldx
