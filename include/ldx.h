@@ -135,6 +135,11 @@ int ldx_vae_create(const ldx_vae_config* cfg, int device, ldx_engine** out);
 /* VAE.decode (VariationalAE.py:690-722): z [B][z_channels][h][w] fp32 (already divided by the latent scale) ->
  * clamp((decoder(post_quant_conv(z)) + 1) / 2, 0, 1) as NHWC fp32 [B][8h][8w][3]. */
 int ldx_vae_decode(ldx_engine* e, const float* z_nchw, int B, int h, int w, float* out_nhwc, void* stream);
+/* VAE.encode's deterministic part (VariationalAE.py:725-760, Encoder.forward :378-413, quant_conv :160-166): pixels
+ * [B][H][W][3] fp32 in [0,1] -> process_input (x*2-1) -> Encoder -> quant_conv -> moments [B][2*z_channels][H/8][W/8]
+ * fp32 (mean | logvar).  Needs the "encoder.*" / "quant_conv.*" tensors to have been loaded.  The stochastic
+ * DiagonalGaussianRegularizer.sample (VariationalAE.py:42-51, global CPU RNG) stays on the host. */
+int ldx_vae_encode(ldx_engine* e, const float* pixels_nhwc, int B, int H, int W, float* moments_nchw, void* stream);
 /* Keys: the transformer's state dict with the "text_model." prefix stripped ("embeddings.token_embedding.weight",
  * "encoder.layers.0.self_attn.q_proj.weight", ..., "final_layer_norm.weight"). */
 int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
@@ -164,6 +169,11 @@ int ldx_flux_forward(ldx_engine* e, const float* x, const float* sigma, const fl
  * Same fp32 operation order as the reference expressions, no FMA contraction.  denoised_out may be NULL. */
 int ldx_sampler_step(int kind, float* x, const float* den_uncond, const float* den_cond, float* denoised_out,
                      int64_t n, float cfg, float c0, float c1, void* stream);
+/* One pass of bislerp (src/Utilities/upscale.py:5-128; LatentUpscale for HiresFix, pipeline.py:346-366): slerp of the
+ * C-vector (C <= 16) between source indices c1[i], c2[i] with ratio ratios[i] along axis 1 (width) or 0 (height);
+ * fp32 NCHW in/out.  The index/ratio arrays are built by the host exactly as generate_bilinear_data does. */
+int ldx_bislerp_pass(const float* in, float* out, int N, int C, int H, int W, int axis, int new_len,
+                     const int32_t* c1, const int32_t* c2, const float* ratios, void* stream);
 /* F.interpolate(mode="bilinear", align_corners=False) on fp32 [planes][H][W] (samplers.py:227-241). */
 int ldx_bilinear(const float* in, float* out, int planes, int hin, int win, int hout, int wout, void* stream);
 

@@ -173,10 +173,23 @@ int ldx_set_graph_mode(ldx_engine* e, int enable) {
 }
 
 int ldx_sampler_step(int kind, float* x, const float* du, const float* dc, float* dout, int64_t n, float cfg, float c0, float c1, void* stream) {
-    if (!x || !du || !dc || n < 0 || (kind < 0 || kind > 2)) { set_error("ldx_sampler_step: bad argument"); return LDX_EINVAL; }
+    if (!x || !du || !dc || n < 0 || (kind < 0 || kind > 3)) { set_error("ldx_sampler_step: bad argument"); return LDX_EINVAL; }
     StepArgs a{x, du, dc, dout, (size_t)n, cfg, kind, c0, c1};
     launch_sampler_step(a, (hipStream_t)stream);
     return check_launch("ldx_sampler_step");
+}
+int ldx_bislerp_pass(const float* in, float* out, int N, int C, int H, int W, int axis, int new_len,
+                     const int32_t* c1, const int32_t* c2, const float* ratios, void* stream) {
+    if (!in || !out || !c1 || !c2 || !ratios || N <= 0 || C <= 0 || C > 16 || H <= 0 || W <= 0 || new_len <= 0 || (axis != 0 && axis != 1)) {
+        set_error("ldx_bislerp_pass: bad argument (C <= 16, axis 0|1)"); return LDX_EINVAL; }
+    launch_bislerp_pass(in, out, N, C, H, W, axis, new_len, (const int*)c1, (const int*)c2, ratios, (hipStream_t)stream);
+    return check_launch("ldx_bislerp_pass");
+}
+int ldx_vae_encode(ldx_engine* e, const float* pixels_nhwc, int B, int H, int W, float* moments_nchw, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_vae_encode(pixels_nhwc, B, H, W, moments_nchw, (hipStream_t)stream);
+    GUARD_END
 }
 int ldx_bilinear(const float* in, float* out, int planes, int hin, int win, int hout, int wout, void* stream) {
     if (!in || !out || planes <= 0 || hin <= 0 || win <= 0 || hout <= 0 || wout <= 0) { set_error("ldx_bilinear: bad argument"); return LDX_EINVAL; }

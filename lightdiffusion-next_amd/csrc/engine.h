@@ -37,6 +37,7 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
+              OP_PIXPREP, OP_MOMENTS,
               OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3 };
 struct Op {
@@ -76,6 +77,8 @@ public:
     int plan_vae(int B, int h, int w);
     int plan_clip(int B, int T, int inter);
     int run_vae(const float* z, int B, int h, int w, float* out_nhwc, hipStream_t st);
+    int plan_vae_encode(int B, int H, int W);
+    int run_vae_encode(const float* px, int B, int H, int W, float* moments, hipStream_t st);
     int run_clip(const int* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, hipStream_t st);
     ~Engine();
     int validate() const;
@@ -121,6 +124,11 @@ private:
     // VAE
     std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
     ResW vae_mid1, vae_mid2; VaeAttnW vae_attn; NormW vae_norm_out; float* vae_pq = nullptr;
+    // VAE encoder (optional: only when encoder.* weights were loaded)
+    bool vae_has_enc = false; int vae_plan_mode = 0;      // 1 decode plan, 2 encode plan
+    std::vector<std::vector<ResW>> enc_down; std::vector<LinearW> enc_downconv;
+    ResW enc_mid1, enc_mid2; VaeAttnW enc_attn; NormW enc_norm_out; LinearW enc_conv_in, enc_conv_out; float* enc_qc = nullptr;
+    bool mk_vae_attn(const std::string& pre, int C, VaeAttnW& a);
     // Flux
     std::vector<FluxDoubleW> fx_double; std::vector<FluxSingleW> fx_single;
     LinearW fx_img_in, fx_txt_in, fx_time0, fx_time1, fx_vec0, fx_vec1, fx_gd0, fx_gd1, fx_mod_all, fx_final;

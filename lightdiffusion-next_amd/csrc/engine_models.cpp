@@ -44,6 +44,25 @@ bool Engine::mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     return true;
 }
 
+bool Engine::mk_vae_attn(const std::string& pre, int C, VaeAttnW& a) {
+    if (!mk_norm(pre + ".norm", C, a.norm) || !mk_linear(pre + ".q", C, C, true, a.q, true) || !mk_linear(pre + ".k", C, C, true, a.k, true)) return false;
+    // v is used as the A operand (V^T = Wv . h^T); its bias is folded through the softmax (rows sum to 1)
+    // into the output projection's bias: b' = Wp . bv + bp.
+    if (!mk_linear(pre + ".v", C, C, false, a.v, true)) return false;
+    const HostTensor* wp = get(pre + ".proj_out.weight", {C, C, 1, 1});
+    const HostTensor* bp = get(pre + ".proj_out.bias", {C});
+    const HostTensor* bv = get(pre + ".v.bias", {C});
+    if (!wp || !bp || !bv) return false;
+    a.proj.N = C; a.proj.K = C;
+    a.proj.w = upload16(C, C, [&](size_t r, size_t c) { return wp->at(r * C + c); });
+    a.proj.b = upload32(C, [&](size_t i) {
+        double acc = bp->at(i);
+        for (int k = 0; k < C; ++k) acc += (double)wp->at(i * C + k) * (double)bv->at(k);
+        return (float)acc;
+    });
+    return a.proj.w && a.proj.b;
+}
+
 int Engine::finalize_vae() {
     if (finalized) return LDX_OK;
     const ldx_vae_config& v = vcfg;
@@ -55,28 +74,7 @@ int Engine::finalize_vae() {
     int block_in = v.ch * v.ch_mult[v.num_levels - 1];
     ok = ok && mk_conv3("decoder.conv_in", block_in, v.z_channels, 64, conv_in);
     ok = ok && mk_vae_res("decoder.mid.block_1", block_in, block_in, vae_mid1);
-    ok = ok && mk_norm("decoder.mid.attn_1.norm", block_in, vae_attn.norm);
-    ok = ok && mk_linear("decoder.mid.attn_1.q", block_in, block_in, true, vae_attn.q, true);
-    ok = ok && mk_linear("decoder.mid.attn_1.k", block_in, block_in, true, vae_attn.k, true);
-    // v is used as the A operand (V^T = Wv . h^T); its bias is folded through the softmax (rows sum to 1)
-    // into the output projection's bias: b' = Wp . bv + bp.
-    ok = ok && mk_linear("decoder.mid.attn_1.v", block_in, block_in, false, vae_attn.v, true);
-    if (ok) {
-        const HostTensor* wp = get("decoder.mid.attn_1.proj_out.weight", {block_in, block_in, 1, 1});
-        const HostTensor* bp = get("decoder.mid.attn_1.proj_out.bias", {block_in});
-        const HostTensor* bv = get("decoder.mid.attn_1.v.bias", {block_in});
-        ok = wp && bp && bv;
-        if (ok) {
-            vae_attn.proj.N = block_in; vae_attn.proj.K = block_in;
-            vae_attn.proj.w = upload16(block_in, block_in, [&](size_t r, size_t c) { return wp->at(r * block_in + c); });
-            vae_attn.proj.b = upload32(block_in, [&](size_t i) {
-                double acc = bp->at(i);
-                for (int k = 0; k < block_in; ++k) acc += (double)wp->at(i * block_in + k) * (double)bv->at(k);
-                return (float)acc;
-            });
-            ok = vae_attn.proj.w && vae_attn.proj.b;
-        }
-    }
+    ok = ok && mk_vae_attn("decoder.mid.attn_1", block_in, vae_attn);
     ok = ok && mk_vae_res("decoder.mid.block_2", block_in, block_in, vae_mid2);
     vae_up.assign(v.num_levels, {}); vae_upconv.assign(v.num_levels, LinearW{}); vae_has_up.assign(v.num_levels, false);
     for (int lv = v.num_levels - 1; ok && lv >= 0; --lv) {
@@ -101,6 +99,34 @@ int Engine::finalize_vae() {
             const int zc = v.z_channels;
             vae_pq = upload32((size_t)zc * zc + zc, [&](size_t i) { return i < (size_t)zc * zc ? w->at(i) : b->at(i - (size_t)zc * zc); });
             ok = vae_pq != nullptr;
+        }
+    }
+    // ---- optional encoder (Encoder.__init__, VariationalAE.py:257-377) ----
+    if (ok && host.count("encoder.conv_in.weight")) {
+        vae_has_enc = true;
+        const int in_px = 3;
+        ok = mk_conv3("encoder.conv_in", v.ch, in_px, 64, enc_conv_in);
+        enc_down.assign(v.num_levels, {}); enc_downconv.assign(v.num_levels, LinearW{});
+        int bin = v.ch;
+        for (int lv = 0; ok && lv < v.num_levels; ++lv) {
+            const int bout = v.ch * v.ch_mult[lv];
+            for (int i = 0; ok && i < v.num_res_blocks; ++i) {
+                ResW r;
+                ok = mk_vae_res("encoder.down." + std::to_string(lv) + ".block." + std::to_string(i), bin, bout, r);
+                enc_down[lv].push_back(r);
+                bin = bout;
+            }
+            if (ok && lv != v.num_levels - 1) ok = mk_conv3("encoder.down." + std::to_string(lv) + ".downsample.conv", bin, bin, bin, enc_downconv[lv]);
+        }
+        ok = ok && mk_vae_res("encoder.mid.block_1", bin, bin, enc_mid1) && mk_vae_attn("encoder.mid.attn_1", bin, enc_attn) &&
+             mk_vae_res("encoder.mid.block_2", bin, bin, enc_mid2) && mk_norm("encoder.norm_out", bin, enc_norm_out) &&
+             mk_conv3("encoder.conv_out", 2 * v.z_channels, bin, bin, enc_conv_out);
+        if (ok && v.use_post_quant) {
+            const int zc2 = 2 * v.z_channels;
+            const HostTensor* w = get("quant_conv.weight", {zc2, zc2, 1, 1});
+            const HostTensor* b = get("quant_conv.bias", {zc2});
+            ok = w && b;
+            if (ok) { enc_qc = upload32((size_t)zc2 * zc2 + zc2, [&](size_t i) { return i < (size_t)zc2 * zc2 ? w->at(i) : b->at(i - (size_t)zc2 * zc2); }); ok = enc_qc != nullptr; }
         }
     }
     if (!ok) {
@@ -192,7 +218,7 @@ int Engine::plan_vae(int B, int h, int w) {
         { Op o{}; o.kind = OP_CLAMP; o.name = "vae.clamp"; o.p0 = pix; o.i0 = B * H * W * v.out_ch; ops.push_back(o); }
         if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
     }
-    pB2 = B; ph = h; pw = w; pM = 0;
+    pB2 = B; ph = h; pw = w; pM = 0; vae_plan_mode = 1;
     return LDX_OK;
 }
 
@@ -201,12 +227,83 @@ int Engine::run_vae(const float* z, int B, int h, int w, float* out, hipStream_t
     if (!z || !out || B <= 0 || h <= 0 || w <= 0) { set_error("ldx_vae_decode: bad argument"); return LDX_EINVAL; }
     if ((h * w) % 8) { set_error("ldx_vae_decode: h*w must be a multiple of 8 (attention row length)"); return LDX_EINVAL; }
     HIP_OK(hipSetDevice(device));
-    if (B != pB2 || h != ph || w != pw) {
+    if (B != pB2 || h != ph || w != pw || vae_plan_mode != 1) {
         HIP_OK(hipStreamSynchronize(st));
         int rc = plan_vae(B, h, w);
         if (rc) return rc;
     }
     b_x = z; b_out = out; prof_graph = false;
+    int rc = exec_ops(st);
+    if (rc) return rc;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    return LDX_OK;
+}
+
+// Encoder.forward (VariationalAE.py:378-413) + quant_conv: pixels -> moments
+int Engine::plan_vae_encode(int B, int Hpx, int Wpx) {
+    const ldx_vae_config& v = vcfg;
+    for (int pass = 0; pass < 2; ++pass) {
+        ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
+        if (pass == 1) {
+            if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
+            if (!arena) { HIP_OK(hipMalloc(&arena, arena_peak_dry)); arena_cap = arena_peak_dry; }
+        }
+        void* saved = arena;
+        if (pass == 0) arena = nullptr;
+        gn_ws_off = a_alloc((size_t)B * GN_NCHUNK * 32 * 2 * 4);
+        int H = Hpx, W = Wpx;
+        Act x0 = new_act(B * H * W, 64);
+        { Op o{}; o.kind = OP_PIXPREP; o.name = "vae.enc.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = 3; o.i2 = H * W; o.i3 = 64; ops.push_back(o); }
+        Act hcur = new_act(B * H * W, v.ch);
+        op_conv("vae.enc.conv_in", x0, B, H, W, 64, enc_conv_in, 1, H, W, hcur, Act{});
+        flops -= 2.0 * B * H * W * (double)v.ch * 9.0 * (64 - 3);
+        release(x0);
+        auto res = [&](const ResW& r) { Act o = new_act(B * H * W, r.Cout); emit_res(r, hcur, o, B, H, W); release(hcur); hcur = o; };
+        for (int lv = 0; lv < v.num_levels; ++lv) {
+            for (auto& r : enc_down[lv]) res(r);
+            if (lv != v.num_levels - 1) {
+                // Downsample: F.pad(x, (0,1,0,1)) then 3x3 stride-2 conv without padding (VariationalAE.py:224-254)
+                const int Cc = enc_down[lv].back().Cout, Ho = H / 2, Wo = W / 2;
+                Act o = new_act(B * Ho * Wo, Cc);
+                op_conv("vae.enc.down", hcur, B, H, W, Cc, enc_downconv[lv], 2, Ho, Wo, o, Act{});
+                ops.back().g.pad0 = 1;
+                release(hcur); hcur = o; H = Ho; W = Wo;
+            }
+        }
+        res(enc_mid1);
+        { Act o = new_act(B * H * W, enc_mid1.Cout); emit_vae_attn(enc_attn, hcur, o, B, H, W); release(hcur); hcur = o; }
+        res(enc_mid2);
+        const int Cl = enc_mid2.Cout, zc2 = 2 * v.z_channels;
+        Act t = new_act(B * H * W, Cl);
+        op_gn("vae.enc.norm_out", hcur, t, B, H * W, enc_norm_out, 1e-6f, true);
+        release(hcur);
+        const size_t o_m = a_alloc((size_t)B * H * W * zc2 * 4);
+        float* mom = (float*)((uintptr_t)arena + o_m);
+        op_conv("vae.enc.conv_out", t, B, H, W, Cl, enc_conv_out, 1, H, W, Act{}, Act{}, nullptr, 0, mom, zc2);
+        release(t);
+        { Op o{}; o.kind = OP_MOMENTS; o.name = "vae.enc.quant_conv"; o.p0 = mom; o.i0 = B; o.i1 = zc2; o.i2 = H * W; ops.push_back(o); }
+        if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
+    }
+    pB2 = B; ph = Hpx; pw = Wpx; pM = 0; vae_plan_mode = 2;
+    return LDX_OK;
+}
+
+int Engine::run_vae_encode(const float* px, int B, int H, int W, float* moments, hipStream_t st) {
+    if (!finalized || kind != KIND_VAE) { set_error("ldx_vae_encode: not a finalized VAE engine"); return LDX_ESTATE; }
+    if (!vae_has_enc) { set_error("ldx_vae_encode: encoder.* weights were not loaded"); return LDX_EMISSING; }
+    const int f = 1 << (vcfg.num_levels - 1);
+    // sizes that are not multiples of f are legal in the reference (vae_encode_crop_pixels is a no-op, VariationalAE.py:
+    // 677-688): every Downsample yields floor(H/2)
+    if (!px || !moments || B <= 0 || H < f || W < f || ((H / f) * (W / f)) % 8) {
+        set_error("ldx_vae_encode: bad argument (H, W >= downscale factor; latent h*w multiple of 8)"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    if (B != pB2 || H != ph || W != pw || vae_plan_mode != 2) {
+        HIP_OK(hipStreamSynchronize(st));
+        int rc = plan_vae_encode(B, H, W);
+        if (rc) return rc;
+    }
+    b_x = px; b_out = moments; prof_graph = false;
     int rc = exec_ops(st);
     if (rc) return rc;
     hipError_t e = hipGetLastError();

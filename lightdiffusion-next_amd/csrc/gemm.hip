@@ -65,7 +65,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const int hw = (MODE == 1) ? p.Hout * p.Wout : 1;
     const int b0 = (MODE == 1) ? m0 / hw : 0;
     const long img = (long)p.Hin * p.Win * p.lda;                       // conv: elements per input image
-    const long a_base = (MODE == 0) ? (long)m0 * p.lda : (long)b0 * img;
+    // conv: the buffer window starts at the first input row this tile can touch, so that in-window byte offsets
+    // stay far below 2^31 even when one image is >= 2 GiB (VAE decode at 2048^2: 2048*2048*256 ch * 2 B)
+    int row0 = 0;
+    if (MODE == 1) {
+        const int oy0 = (m0 - b0 * hw) / p.Wout;
+        row0 = max(oy0 * p.stride - (p.pad0 ? 0 : 1), 0);
+        if (p.resize) row0 = min((int)floorf((float)row0 * ((float)p.Hin / (float)p.Hv)), p.Hin - 1);
+    }
+    const long a_base = (MODE == 0) ? (long)m0 * p.lda : (long)b0 * img + (long)row0 * p.Win * p.lda;
     const long a_total = (MODE == 0) ? (long)(p.M - 1) * p.lda + p.K : ((long)(p.M / hw) * p.Hin * p.Win - 1) * p.lda + p.Cin;
     const long a_rem = (a_total - a_base) * 2;
     const long w_rem = ((long)p.N * p.K - (long)n0 * p.K) * 2;
@@ -86,8 +94,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             const int b = m / hw, rem = m - b * hw;
             const int oy = rem / p.Wout, ox = rem - oy * p.Wout;
             a_pix[j] = ok ? (int)(((long)(b - b0) * img + schunk * 8) * 2) : OOB;
-            a_oy[j] = oy * p.stride - 1;
-            a_ox[j] = ox * p.stride - 1;
+            a_oy[j] = oy * p.stride - (p.pad0 ? 0 : 1);
+            a_ox[j] = ox * p.stride - (p.pad0 ? 0 : 1);
             a_voff[j] = OOB;
         }
     }
@@ -128,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                         iy = min((int)floorf((float)iy * rs_y), p.Hin - 1);
                         ix = min((int)floorf((float)ix * rs_x), p.Win - 1);
                     }
-                    a_voff[j] = ok ? a_pix[j] + (iy * p.Win + ix) * p.lda * 2 : OOB;
+                    a_voff[j] = ok ? a_pix[j] + ((iy - row0) * p.Win + ix) * p.lda * 2 : OOB;
                 }
             }
             const int soff = st_ci * 2;

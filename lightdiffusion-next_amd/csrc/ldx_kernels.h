@@ -30,6 +30,7 @@ struct GemmArgs {
     int Hv, Wv;                    // conv: virtual (resized) input extent seen by the 3x3 window
     int Hout, Wout, stride;        // conv: output extent
     int resize;                    // conv: 1 if (Hv,Wv) != (Hin,Win) -> nearest gather
+    int pad0;                      // conv: 1 -> no top/left padding (VAE Downsample: F.pad (0,1,0,1) + stride-2 conv, VariationalAE.py:224-254)
     const float* bias;             // [N] or null
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
     int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2
@@ -113,6 +114,8 @@ void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int C
 // VAE boundary (AutoEncoders/VariationalAE.py:130-145, 690-722): z fp32 NCHW [B][C][HW] -> optional 1x1 mix
 // (post_quant_conv, fp32: out[c] = b[c] + sum_k w[c][k] z[k]) -> NHWC 16-bit with Cpad channels.
 void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, const float* mix_w, const float* mix_b, DType dt, hipStream_t s);
+// encoder input: pixels NHWC fp32 [B][HW][C] in [0,1] -> x*2-1 (process_input, VariationalAE.py:593) -> NHWC 16-bit, Cpad channels
+void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, DType dt, hipStream_t s);
 // pixel post-process: out = clamp((x + 1) / 2, 0, 1) on fp32 (process_output, VariationalAE.py:595-597)
 void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s);
 // row softmax in place on a 16-bit [rows][ld] matrix: p = softmax(x * scale) (VAE AttnBlock, D = 512 single head)
@@ -141,6 +144,7 @@ void launch_flux_unpatchify(const float* tok, int ld, const float* x, const floa
 //  kind 0 euler: x = x + ((x - d) / c0) * c1   c0 = sigma_hat, c1 = sigma_next - sigma_hat (samplers.py:308, util.py:26-37)
 //  kind 1 dpmpp: x = c0 * x - c1 * d           c0 = sigma_next/sigma, c1 = expm1(-h)       (samplers.py:945-946)
 //  kind 2      : denoised_out = d only (multiscale steps combine at low resolution first)
+//  kind 3      : x = x + den_uncond * c0   (ancestral noise injection: x + noise * s_noise * sigma_up, samplers.py:728-729)
 // den_*: the two [B] chunks [uncond; cond] returned by the wrapper (cond.py:194-195 order).
 struct StepArgs {
     float* x; const float* den_uncond; const float* den_cond; float* denoised_out;  // denoised_out optional
@@ -148,6 +152,12 @@ struct StepArgs {
     float c0, c1;
 };
 void launch_sampler_step(const StepArgs& a, hipStream_t s);
+// one pass of bislerp (Utilities/upscale.py:5-128): per-pixel spherical interpolation of the C-vector between source
+// positions c1[i], c2[i] with ratio r[i] along the last (axis = 1) or second-to-last (axis = 0) spatial axis.
+void launch_bislerp_pass(const float* in, float* out, int N, int C, int H, int W, int axis, int new_len,
+                         const int* c1, const int* c2, const float* r, hipStream_t s);
+// VAE encoder tail: moments_nchw[b][c][p] = bias[c] + sum_k w[c][k] * in_nhwc[b][p][k]   (quant_conv 1x1, fp32)
+void launch_mix_nhwc_to_nchw(const float* in, int ld, float* out, int B, int C, int HW, const float* w, const float* bias, hipStream_t s);
 // bilinear resize (align_corners=False, antialias=False) of fp32 NCHW planes
 void launch_bilinear(const float* in, float* out, int planes, int Hin, int Win, int Hout, int Wout, hipStream_t s);
 

@@ -163,6 +163,25 @@ void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, 
     else hipLaunchKernelGGL((vae_prep_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, z, (_Float16*)out, B, C, HW, Cpad, mw, mb);
 }
 
+template <typename T>
+__global__ __launch_bounds__(256) void pixels_prep_kernel(const float* px, T* out, int B, int C, int HW, int Cpad) {
+    const int cpp = Cpad / 8;
+    const long total = (long)B * HW * cpp;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % cpp);
+        const long bp = idx / cpp;
+        float f[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const int c = ch * 8 + e; f[e] = c < C ? px[bp * C + c] * 2.0f - 1.0f : 0.f; }
+        *(uint4*)(out + bp * Cpad + ch * 8) = pack8<T>(f);
+    }
+}
+void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * HW * (Cpad / 8);
+    if (dt == DT_BF16) hipLaunchKernelGGL((pixels_prep_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, px, (__bf16*)out, B, C, HW, Cpad);
+    else hipLaunchKernelGGL((pixels_prep_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, px, (_Float16*)out, B, C, HW, Cpad);
+}
+
 __global__ __launch_bounds__(256) void clamp01_kernel(const float* in, float* out, size_t n) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256)
         out[i] = fminf(fmaxf((in[i] + 1.0f) / 2.0f, 0.0f), 1.0f);
@@ -292,6 +311,7 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs p) {
         const float d = (fabsf(p.cfg) < 0.5f) ? (u + p.cfg * diff) : (c - diff * (1.0f - p.cfg));
         if (p.denoised_out) p.denoised_out[i] = d;
         if (p.kind == 2) continue;                           // CFG combine only
+        if (p.kind == 3) { p.x[i] = p.x[i] + u * p.c0; continue; }   // noise injection (den_uncond = noise)
         const float x = p.x[i];
         float xn;
         if (p.kind == 0) xn = x + ((x - d) / p.c0) * p.c1;   // c0 = sigma_hat, c1 = sigma_next - sigma_hat
@@ -302,6 +322,61 @@ __global__ __launch_bounds__(256) void sampler_step_kernel(const StepArgs p) {
 #pragma clang fp contract(fast)
 void launch_sampler_step(const StepArgs& a, hipStream_t s) {
     hipLaunchKernelGGL(sampler_step_kernel, dim3(grid_for(a.n)), dim3(256), 0, s, a);
+}
+
+// slerp of upscale.py:8-40, one output pixel per thread (C <= 16 channels)
+__global__ __launch_bounds__(256) void bislerp_kernel(const float* in, float* out, int N, int C, int H, int W, int axis, int L,
+                                                      const int* c1, const int* c2, const float* rt) {
+    const int Ho = axis == 0 ? L : H, Wo = axis == 1 ? L : W;
+    const long total = (long)N * Ho * Wo;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int xo = (int)(idx % Wo), yo = (int)((idx / Wo) % Ho), n = (int)(idx / ((long)Wo * Ho));
+        const int i = axis == 1 ? xo : yo;
+        const float r = rt[i];
+        const int y1 = axis == 0 ? c1[i] : yo, y2 = axis == 0 ? c2[i] : yo, x1 = axis == 1 ? c1[i] : xo, x2 = axis == 1 ? c2[i] : xo;
+        float b1[16], b2[16];
+        float n1 = 0.f, n2 = 0.f;
+        for (int c = 0; c < C; ++c) {
+            b1[c] = in[(((long)n * C + c) * H + y1) * W + x1];
+            b2[c] = in[(((long)n * C + c) * H + y2) * W + x2];
+            n1 += b1[c] * b1[c]; n2 += b2[c] * b2[c];
+        }
+        n1 = sqrtf(n1); n2 = sqrtf(n2);
+        float dot = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float u = n1 == 0.f ? 0.f : b1[c] / n1, v = n2 == 0.f ? 0.f : b2[c] / n2;
+            dot += u * v;
+        }
+        const float omega = acosf(dot), so = sinf(omega);
+        const float w1 = sinf((1.0f - r) * omega) / so, w2 = sinf(r * omega) / so;
+        const float nm = n1 * (1.0f - r) + n2 * r;
+        for (int c = 0; c < C; ++c) {
+            const float u = n1 == 0.f ? 0.f : b1[c] / n1, v = n2 == 0.f ? 0.f : b2[c] / n2;
+            float res = (w1 * u + w2 * v) * nm;
+            if (dot > 1.0f - 1e-5f) res = b1[c];
+            if (dot < 1e-5f - 1.0f) res = b1[c] * (1.0f - r) + b2[c] * r;
+            out[(((long)n * C + c) * Ho + yo) * Wo + xo] = res;
+        }
+    }
+}
+void launch_bislerp_pass(const float* in, float* out, int N, int C, int H, int W, int axis, int new_len,
+                         const int* c1, const int* c2, const float* r, hipStream_t s) {
+    const size_t total = (size_t)N * (axis == 0 ? new_len : H) * (axis == 1 ? new_len : W);
+    hipLaunchKernelGGL(bislerp_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, N, C, H, W, axis, new_len, c1, c2, r);
+}
+
+__global__ __launch_bounds__(256) void mix_nhwc_to_nchw_kernel(const float* in, int ld, float* out, int B, int C, int HW, const float* w, const float* bias) {
+    const long total = (long)B * C * HW;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int p = (int)(idx % HW), c = (int)((idx / HW) % C), b = (int)(idx / ((long)HW * C));
+        const float* src = in + ((long)b * HW + p) * ld;
+        float v = bias ? bias[c] : 0.f;
+        if (w) { for (int k = 0; k < C; ++k) v += w[c * C + k] * src[k]; } else v += src[c];
+        out[idx] = v;
+    }
+}
+void launch_mix_nhwc_to_nchw(const float* in, int ld, float* out, int B, int C, int HW, const float* w, const float* bias, hipStream_t s) {
+    hipLaunchKernelGGL(mix_nhwc_to_nchw_kernel, dim3(grid_for((size_t)B * C * HW)), dim3(256), 0, s, in, ld, out, B, C, HW, w, bias);
 }
 
 // torch upsample_bilinear2d, align_corners=False: src = max((dst + .5) * in/out - .5, 0)

@@ -160,11 +160,67 @@ class VAEDecoderEngine:
                   "ldx_vae_decode")
         return out
 
+    def encode_moments(self, pixels):
+        """Deterministic part of VAE.encode (VariationalAE.py:725-760): pixels [B,H,W,3] fp32 in [0,1] ->
+        moments [B, 2*z, H/8, W/8] (mean | logvar).  Needs encoder.* / quant_conv.* in the state dict."""
+        assert pixels.is_cuda and pixels.dtype == torch.float32 and pixels.dim() == 4 and pixels.shape[-1] == 3
+        b, h, w, _ = pixels.shape
+        f = 2 ** (len(self.cfg.ch_mult) - 1)
+        out = torch.empty((b, 2 * self.cfg.z_channels, h // f, w // f), device=pixels.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_vae_encode(self._h, lib.ptr(pixels.contiguous()), b, h, w, lib.ptr(out), lib.current_stream_ptr()),
+                  "ldx_vae_encode")
+        return out
+
+    def encode(self, pixels):
+        """VAE.encode (VariationalAE.py:725-760).  vae_encode_crop_pixels (:677-688) computes the cropped sizes and
+        throws them away, so nothing is cropped: every Downsample floors.  Then DiagonalGaussianDistribution.sample
+        (:42-51) — torch.randn(mean.shape) from the *global CPU RNG* exactly as the reference draws it, uploaded."""
+        mom = self.encode_moments(pixels[..., :3].to(self.device, torch.float32))
+        mean, logvar = torch.chunk(mom, 2, dim=1)
+        eps = torch.randn(mean.shape).to(self.device)
+        return mean + torch.exp(0.5 * torch.clamp(logvar, -30.0, 20.0)) * eps
+
     profile = UNetEngine.profile
     profile_report = UNetEngine.profile_report
     plan_info = UNetEngine.plan_info
     close = UNetEngine.close
     __del__ = UNetEngine.__del__
+
+
+def _bislerp_data(length_old: int, length_new: int):
+    """generate_bilinear_data (src/Utilities/upscale.py:61-97): the reference builds the index / ratio arrays with
+    F.interpolate(mode="bilinear") of an arange; reproduced verbatim on the host (length_new floats)."""
+    c1 = torch.arange(length_old, dtype=torch.float32).reshape(1, 1, 1, -1)
+    c1 = torch.nn.functional.interpolate(c1, size=(1, length_new), mode="bilinear")
+    ratios = (c1 - c1.floor()).reshape(-1)
+    c2 = torch.arange(length_old, dtype=torch.float32).reshape(1, 1, 1, -1) + 1
+    c2[:, :, :, -1] -= 1
+    c2 = torch.nn.functional.interpolate(c2, size=(1, length_new), mode="bilinear")
+    return ratios.contiguous(), c1.reshape(-1).to(torch.int32), c2.reshape(-1).to(torch.int32)
+
+
+def bislerp(samples, width: int, height: int):
+    """bislerp (src/Utilities/upscale.py:5-128) = LatentUpscale.upscale's resampler (HiresFix, pipeline.py:346-350):
+    a slerp pass along W then one along H, each one ldx_bislerp_pass launch on fp32 NCHW device tensors."""
+    assert samples.is_cuda and samples.dim() == 4
+    L = lib.load()
+    x = samples.float().contiguous()
+    n, c, h, w = x.shape
+    dev = x.device
+    r, c1, c2 = (t.to(dev) for t in _bislerp_data(w, width))
+    y = torch.empty((n, c, h, width), device=dev, dtype=torch.float32)
+    lib.check(L.ldx_bislerp_pass(lib.ptr(x), lib.ptr(y), n, c, h, w, 1, width, lib.ptr(c1), lib.ptr(c2), lib.ptr(r),
+                                 lib.current_stream_ptr()), "ldx_bislerp_pass")
+    r2, d1, d2 = (t.to(dev) for t in _bislerp_data(h, height))
+    z = torch.empty((n, c, height, width), device=dev, dtype=torch.float32)
+    lib.check(L.ldx_bislerp_pass(lib.ptr(y), lib.ptr(z), n, c, h, width, 0, height, lib.ptr(d1), lib.ptr(d2), lib.ptr(r2),
+                                 lib.current_stream_ptr()), "ldx_bislerp_pass")
+    return z.to(samples.dtype)
+
+
+def latent_upscale(samples, width: int, height: int):
+    """LatentUpscale.upscale (upscale.py:149-166): target latent size = pixel size // 8."""
+    return bislerp(samples, width // 8, height // 8)
 
 
 class CLIPTextEngine:

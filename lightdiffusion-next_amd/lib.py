@@ -71,6 +71,8 @@ _SIGS = {
     "ldx_flux_create": (_i, [C.POINTER(ldx_flux_config), _i, C.POINTER(_vp)]),
     "ldx_flux_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldx_sampler_step": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
+    "ldx_bislerp_pass": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
+    "ldx_vae_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_bilinear": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp]),
     "ldx_op_convert": (_i, [_vp, _vp, _i64, _i, _i, _vp]),
     "ldx_op_gemm": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),

@@ -280,6 +280,37 @@ def sample_dpmpp_2m_cfgpp(model, x, sigmas, enable_multiscale=True, multiscale_f
     return x
 
 
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """sampling_util.get_ancestral_step (sampling_util.py:128-151) on fp32 tensor scalars."""
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+@torch.no_grad()
+def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler=None, trace=None):
+    """samplers.sample_euler_ancestral_dy_cfg_pp (samplers.py:612-733) with its defaults.  The CFG++ branch is dead
+    code in the reference: every step is Euler to sigma_down on the guider's ordinary CFG
+    output, then  x += noise * s_noise * sigma_up  (ldx_sampler_step kind 3).  The reference's default noise sampler
+    is torch.randn_like(x) on the *global* generator (sampling_util.py:154-165); to be reproducible against a CPU run
+    of the reference the noise is drawn here from the global CPU generator in the same order and uploaded (256 KiB
+    per image and step)."""
+    n_steps = len(sigmas) - 1
+    if noise_sampler is None:
+        noise_sampler = lambda s, sn: torch.randn(x.shape, dtype=torch.float32)      # noqa: E731
+    for i in range(n_steps):
+        sigma_hat = sigmas[i]
+        du, dc = model(x, sigma_hat)
+        if trace is not None:
+            trace.append(tuple(x.shape[-2:]))
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        _step(0, x, du, dc, model.cfg, sigma_hat, sigma_down - sigma_hat)
+        if sigmas[i + 1] > 0:
+            nz = noise_sampler(sigmas[i], sigmas[i + 1]).to(x.device, torch.float32).contiguous()
+            _step(3, x, nz, nz, 1.0, s_noise * sigma_up, 0.0)
+    return x
+
+
 _MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -287,8 +318,10 @@ def _resolve_sampler(sampler_name):
     """sampling.ksampler (sampling.py:500-534): only four names are recognised, the rest fall back to Euler."""
     if sampler_name == "dpmpp_2m_cfgpp":
         return sample_dpmpp_2m_cfgpp, True
-    if sampler_name in ("euler_ancestral_cfgpp", "dpmpp_sde_cfgpp", "euler_cfgpp"):
-        raise NotImplementedError(f"sampler '{sampler_name}' draws device-side noise / dy steps; next row (SURVEY §8 a5)")
+    if sampler_name == "euler_ancestral_cfgpp":
+        return sample_euler_ancestral_cfgpp, True
+    if sampler_name in ("dpmpp_sde_cfgpp", "euler_cfgpp"):
+        raise NotImplementedError(f"sampler '{sampler_name}' (Brownian-tree noise / dy extra steps) is a next row (SURVEY §8 a5)")
     return sample_euler, False
 
 

@@ -230,6 +230,46 @@ def vae_decoder_state_dict_spec(cfg: VAEConfig):
     return spec
 
 
+def vae_encoder_state_dict_spec(cfg: VAEConfig, in_channels: int = 3):
+    """Encoder + quant_conv keys in the order Encoder.__init__ creates them (VariationalAE.py:257-377)."""
+    spec = [("encoder.conv_in.weight", (cfg.ch, in_channels, 3, 3)), ("encoder.conv_in.bias", (cfg.ch,))]
+
+    def res(pre, cin, cout):
+        nonlocal spec
+        spec += [(f"{pre}.norm1.weight", (cin,)), (f"{pre}.norm1.bias", (cin,)),
+                 (f"{pre}.conv1.weight", (cout, cin, 3, 3)), (f"{pre}.conv1.bias", (cout,)),
+                 (f"{pre}.norm2.weight", (cout,)), (f"{pre}.norm2.bias", (cout,)),
+                 (f"{pre}.conv2.weight", (cout, cout, 3, 3)), (f"{pre}.conv2.bias", (cout,))]
+        if cin != cout:
+            spec += [(f"{pre}.nin_shortcut.weight", (cout, cin, 1, 1)), (f"{pre}.nin_shortcut.bias", (cout,))]
+
+    nl = len(cfg.ch_mult)
+    block_in = cfg.ch
+    for lv in range(nl):
+        block_out = cfg.ch * cfg.ch_mult[lv]
+        for i in range(cfg.num_res_blocks):
+            res(f"encoder.down.{lv}.block.{i}", block_in, block_out)
+            block_in = block_out
+        if lv != nl - 1:
+            spec += [(f"encoder.down.{lv}.downsample.conv.weight", (block_in, block_in, 3, 3)),
+                     (f"encoder.down.{lv}.downsample.conv.bias", (block_in,))]
+    res("encoder.mid.block_1", block_in, block_in)
+    spec += [("encoder.mid.attn_1.norm.weight", (block_in,)), ("encoder.mid.attn_1.norm.bias", (block_in,))]
+    for n in ("q", "k", "v", "proj_out"):
+        spec += [(f"encoder.mid.attn_1.{n}.weight", (block_in, block_in, 1, 1)), (f"encoder.mid.attn_1.{n}.bias", (block_in,))]
+    res("encoder.mid.block_2", block_in, block_in)
+    spec += [("encoder.norm_out.weight", (block_in,)), ("encoder.norm_out.bias", (block_in,)),
+             ("encoder.conv_out.weight", (2 * cfg.z_channels, block_in, 3, 3)), ("encoder.conv_out.bias", (2 * cfg.z_channels,))]
+    if cfg.use_post_quant:
+        spec += [("quant_conv.weight", (2 * cfg.z_channels, 2 * cfg.z_channels, 1, 1)), ("quant_conv.bias", (2 * cfg.z_channels,))]
+    return spec
+
+
+def vae_state_dict_spec(cfg: VAEConfig):
+    """Full AutoencodingEngine state dict: encoder, decoder, quant / post_quant convs."""
+    return vae_encoder_state_dict_spec(cfg) + vae_decoder_state_dict_spec(cfg)
+
+
 @dataclass
 class CLIPConfig:
     """include/clip/sd1_clip_config.json as read by CLIPTextModel_ (src/clip/CLIPTextModel.py:3-50)."""

@@ -338,6 +338,32 @@ def sample_dpmpp_2m_cfgpp(model, x, sigmas, enable_multiscale=True, multiscale_f
     return x
 
 
+def get_ancestral_step(sigma_from, sigma_to, eta=1.0):
+    """sampling_util.py:128-151."""
+    sigma_up = min(sigma_to, eta * (sigma_to ** 2 * (sigma_from ** 2 - sigma_to ** 2) / sigma_from ** 2) ** 0.5)
+    sigma_down = (sigma_to ** 2 - sigma_up ** 2) ** 0.5
+    return sigma_down, sigma_up
+
+
+def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, trace=None):
+    """samplers.sample_euler_ancestral_dy_cfg_pp (samplers.py:612-733) with its defaults (s_gamma_* = 0 so
+    sigma_hat = sigma_i).  The hand-made post-CFG hook call makes uncond_denoised *be* denoised (SURVEY Appendix
+    A-2), so cfg_denoised == denoised and this is Euler-ancestral on the guider's ordinary CFG output.  Noise comes
+    from default_noise_sampler (sampling_util.py:154-165): torch.randn_like(x) from the *global* RNG, i.e. the
+    stream prepare_noise seeded, continued after the initial noise draw."""
+    n = len(sigmas) - 1
+    for i in range(n):
+        sigma_hat = sigmas[i]
+        if trace is not None:
+            trace.append(tuple(x.shape[-2:]))
+        denoised = model(x, sigma_hat)
+        sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
+        x = x + ((x - denoised) / sigma_hat) * (sigma_down - sigma_hat)
+        if sigmas[i + 1] > 0:
+            x = x + torch.randn_like(x) * s_noise * sigma_up
+    return x
+
+
 MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -354,7 +380,9 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
     sigmas = sigmas_for(scheduler, steps, denoise)
     if sampler_name == "dpmpp_2m_cfgpp":                                                  # sampling.py:517-532
         fn, disable_cfg1 = sample_dpmpp_2m_cfgpp, True
-    elif sampler_name in ("euler_ancestral_cfgpp", "dpmpp_sde_cfgpp", "euler_cfgpp"):
+    elif sampler_name == "euler_ancestral_cfgpp":
+        fn, disable_cfg1 = sample_euler_ancestral_cfgpp, True
+    elif sampler_name in ("dpmpp_sde_cfgpp", "euler_cfgpp"):
         raise NotImplementedError(sampler_name)
     else:
         fn, disable_cfg1 = sample_euler, False
@@ -377,6 +405,53 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
 
     x = fn(model, x, sigmas, trace=trace, **extra)
     return x / 0.18215                                                                    # CFG.py:294
+
+
+# ---------------------------------------------------------------------------------------------------
+# Latent upscale (src/Utilities/upscale.py:5-128), used by HiresFix (pipeline.py:346-350)
+def _bislerp_data(length_old, length_new):
+    """generate_bilinear_data (upscale.py:61-97)."""
+    c1 = torch.arange(length_old, dtype=torch.float32).reshape(1, 1, 1, -1)
+    c1 = F.interpolate(c1, size=(1, length_new), mode="bilinear")
+    ratios = c1 - c1.floor()
+    c1 = c1.to(torch.int64)
+    c2 = torch.arange(length_old, dtype=torch.float32).reshape(1, 1, 1, -1) + 1
+    c2[:, :, :, -1] -= 1
+    c2 = F.interpolate(c2, size=(1, length_new), mode="bilinear").to(torch.int64)
+    return ratios.reshape(-1), c1.reshape(-1), c2.reshape(-1)
+
+
+def _slerp(b1, b2, r):
+    """slerp (upscale.py:17-59) on [P, C] rows with ratio [P, 1]."""
+    n1 = torch.norm(b1, dim=-1, keepdim=True)
+    n2 = torch.norm(b2, dim=-1, keepdim=True)
+    u1 = torch.where(n1 == 0.0, torch.zeros_like(b1), b1 / n1)
+    u2 = torch.where(n2 == 0.0, torch.zeros_like(b2), b2 / n2)
+    dot = (u1 * u2).sum(1)
+    omega = torch.acos(dot)
+    so = torch.sin(omega)
+    res = (torch.sin((1.0 - r.squeeze(1)) * omega) / so).unsqueeze(1) * u1 + (torch.sin(r.squeeze(1) * omega) / so).unsqueeze(1) * u2
+    res = res * (n1 * (1.0 - r) + n2 * r)
+    res = torch.where((dot > 1 - 1e-5).unsqueeze(1), b1, res)
+    res = torch.where((dot < 1e-5 - 1).unsqueeze(1), b1 * (1.0 - r) + b2 * r, res)
+    return res
+
+
+def bislerp(samples, width, height):
+    """bislerp (upscale.py:5-128): slerp along W, then along H, of the channel vector at each pixel."""
+    x = samples.float()
+    n, c, h, w = x.shape
+    r, c1, c2 = _bislerp_data(w, width)
+    p1 = x[:, :, :, c1].movedim(1, -1).reshape(-1, c)
+    p2 = x[:, :, :, c2].movedim(1, -1).reshape(-1, c)
+    rr = r.reshape(1, 1, -1).expand(n, h, -1).reshape(-1, 1)
+    x = _slerp(p1, p2, rr).reshape(n, h, width, c).movedim(-1, 1)
+    r, c1, c2 = _bislerp_data(h, height)
+    p1 = x[:, :, c1, :].movedim(1, -1).reshape(-1, c)
+    p2 = x[:, :, c2, :].movedim(1, -1).reshape(-1, c)
+    rr = r.reshape(1, -1, 1).expand(n, -1, width).reshape(-1, 1)
+    x = _slerp(p1, p2, rr).reshape(n, height, width, c).movedim(-1, 1)
+    return x.to(samples.dtype)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -425,6 +500,39 @@ def vae_decode(sd, cfg, z):
     h = F.silu(group_norm(h, d, "norm_out", 1e-6))
     h = F.conv2d(h, d("conv_out.weight"), d("conv_out.bias"), padding=1)
     return torch.clamp((h + 1.0) / 2.0, min=0.0, max=1.0).movedim(1, -1)
+
+
+def vae_encode_moments(sd, cfg, pixels):
+    """VAE.encode up to the regulariser (VariationalAE.py:725-760): pixels [B,H,W,3] in [0,1] -> process_input
+    (x*2-1, :593) -> Encoder.forward (:378-413; Downsample = F.pad (0,1,0,1) + 3x3 stride-2 pad-0 conv, :224-254)
+    -> quant_conv (:164-166) -> moments [B, 2*z, H/8, W/8] (mean | logvar)."""
+    w = W(sd)
+    e = w.sub("encoder.")
+    x = pixels[..., :3].movedim(-1, 1).float() * 2.0 - 1.0
+    h = F.conv2d(x, e("conv_in.weight"), e("conv_in.bias"), padding=1)
+    nl = len(cfg.ch_mult)
+    for lv in range(nl):
+        for i in range(cfg.num_res_blocks):
+            h = vae_resnet_block(e.sub(f"down.{lv}.block.{i}."), h)
+        if lv != nl - 1:
+            h = F.pad(h, (0, 1, 0, 1), mode="constant", value=0)
+            h = F.conv2d(h, e(f"down.{lv}.downsample.conv.weight"), e(f"down.{lv}.downsample.conv.bias"), stride=2, padding=0)
+    h = vae_resnet_block(e.sub("mid.block_1."), h)
+    h = vae_attn_block(e.sub("mid.attn_1."), h)
+    h = vae_resnet_block(e.sub("mid.block_2."), h)
+    h = F.silu(group_norm(h, e, "norm_out", 1e-6))
+    h = F.conv2d(h, e("conv_out.weight"), e("conv_out.bias"), padding=1)
+    if cfg.use_post_quant:
+        h = F.conv2d(h, w("quant_conv.weight"), w("quant_conv.bias"))
+    return h
+
+
+def vae_sample_moments(moments):
+    """DiagonalGaussianRegularizer / DiagonalGaussianDistribution.sample (VariationalAE.py:34-51): logvar clamped
+    to [-30, 20]; mean + exp(0.5 logvar) * torch.randn(mean.shape) from the global CPU RNG."""
+    mean, logvar = torch.chunk(moments, 2, dim=1)
+    logvar = torch.clamp(logvar, -30.0, 20.0)
+    return mean + torch.exp(0.5 * logvar) * torch.randn(mean.shape)
 
 
 # ---------------------------------------------------------------------------------------------------

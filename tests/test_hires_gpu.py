@@ -1,0 +1,120 @@
+"""HiresFix rows on a real MI355X through libldx.so: bislerp (ldx_bislerp_pass), VAE encode (ldx_vae_encode),
+euler_ancestral_cfgpp (ldx_sampler_step kinds 0 + 3) and the upscale -> resample chain, vs the reference goldens
+(tests/golden/hires.npz) and the oracle.
+
+Tolerances: bislerp is fp32 with device acosf/sinf: abs <= 1e-4 on unit-scale latents.  VAE moments: the engine
+stores activations in 16 bit; rel-L2 <= 4e-3 (fp16) / 2.5e-2 (bf16).  Sampler latents as in test_engine_gpu.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sd15_oracle as O  # noqa: E402  (checker only)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return np.load(os.path.join(golden_dir, "hires.npz"))
+
+
+def test_bislerp_vs_reference_golden(ldx, ldx_lib, g):
+    bislerp, latent_upscale = ldx.bislerp, ldx.latent_upscale
+    for i in range(int(g["bs_n"])):
+        wn, hn = (int(v) for v in g[f"bs_wh_{i}"])
+        out = bislerp(torch.from_numpy(g[f"bs_in_{i}"]).cuda(), wn, hn)
+        err = float((out.cpu() - torch.from_numpy(g[f"bs_out_{i}"])).abs().max())
+        print(f"bislerp case {i}: max abs err {err:.2e}")
+        assert out.shape == g[f"bs_out_{i}"].shape and err <= 1e-4
+    out = latent_upscale(torch.from_numpy(g["bs_in_1"]).cuda(), 256, 192)
+    assert float((out.cpu() - torch.from_numpy(g["lu_out"])).abs().max()) <= 1e-4
+
+
+def test_bislerp_full_size(ldx, ldx_lib):
+    """Config-5 size (latent 128^2 -> 256^2) vs the oracle; same-size is the identity up to the normalise / re-scale
+    rounding; parallel neighbours take the dot > 1 - 1e-5 branch, i.e. the result is b1 (floor-nearest gather)."""
+    bislerp = ldx.bislerp
+    x = torch.randn(1, 4, 128, 128, generator=torch.Generator().manual_seed(0))
+    y = bislerp(x.cuda(), 256, 256)
+    assert float((y.cpu() - O.bislerp(x, 256, 256)).abs().max()) <= 1e-4
+    assert float((bislerp(x.cuda(), 128, 128).cpu() - x).abs().max()) <= 1e-5
+    d = torch.tensor([0.5, -1.0, 2.0, 0.25]).view(1, 4, 1, 1)
+    s = torch.rand(1, 1, 128, 128, generator=torch.Generator().manual_seed(1)) + 0.5
+    y = bislerp((d * s).cuda(), 256, 256).cpu()
+    idx = torch.nn.functional.interpolate(torch.arange(128.0).view(1, 1, 1, -1), size=(1, 256), mode="bilinear").long().view(-1)
+    assert float((y - (d * s)[:, :, idx][:, :, :, idx]).abs().max()) <= 1e-5
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_vae_encode_vs_reference_golden(ldx, ldx_lib, g, dt, tol):
+    for tag in g["enc_tags"]:
+        ch = int(str(tag).split("_")[0])
+        cfg = ldx.VAEConfig(ch=ch)
+        sd = ldx.weights.synth_state_dict(ldx.weights.vae_state_dict_spec(cfg), seed=4321, dtype=torch.float32)
+        eng = ldx.VAEDecoderEngine(cfg, sd, device=0, dtype=dt)
+        px = torch.from_numpy(g[f"enc_px_{tag}"]).cuda()
+        mom = eng.encode_moments(px)
+        r = _rel(mom, g[f"enc_mom_{tag}"])
+        print(f"[{dt}] VAE encode {tag}: moments rel-L2 {r:.3e}")
+        assert mom.shape == g[f"enc_mom_{tag}"].shape and r <= tol
+        torch.manual_seed(5)
+        smp = eng.encode(px)
+        assert _rel(smp, g[f"enc_sample_{tag}"]) <= tol
+        # the same engine still decodes (plan switch encode <-> decode)
+        z = torch.randn(1, 4, 8, 8, generator=torch.Generator().manual_seed(2))
+        img = eng.decode(z.cuda())
+        with torch.no_grad():
+            ref = O.vae_decode(sd, cfg, z)
+        assert float(((img.cpu() - ref) ** 2).mean()) < 1e-3
+
+
+def test_vae_encode_requires_encoder_weights(ldx, ldx_lib):
+    cfg = ldx.VAEConfig(ch=64)
+    sd = ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(cfg), seed=4321, dtype=torch.float32)
+    eng = ldx.VAEDecoderEngine(cfg, sd, device=0, dtype="f16")
+    with pytest.raises(ldx.lib.LdxError):
+        eng.encode_moments(torch.rand(1, 32, 32, 3).cuda())
+
+
+@pytest.fixture(scope="module")
+def unet(ldx, ldx_lib):
+    cfg = ldx.UNetConfig.tiny(64, 128)
+    sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234)
+    return {dt: ldx.UNetEngine(cfg, sd, device=0, dtype=dt) for dt in ("f16", "bf16")}
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_euler_ancestral_cfgpp(ldx, g, unet, dt, tol):
+    ks = ldx.sampling.KSampler(unet[dt])
+    P, N = torch.from_numpy(g["P"]), torch.from_numpy(g["N"])
+    out = ks.sample(seed=5, steps=10, cfg=8.0, denoise=0.45, positive=P, negative=N, latent_image=torch.from_numpy(g["anc_latent"]),
+                    sampler_name="euler_ancestral_cfgpp", scheduler="normal")
+    r1 = _rel(out, g["anc_img2img"])
+    out = ks.sample(seed=6, steps=8, cfg=7.0, denoise=1.0, positive=P, negative=N, latent_image=torch.zeros(1, 4, 16, 16),
+                    sampler_name="euler_ancestral_cfgpp", scheduler="karras")
+    r2 = _rel(out, g["anc_txt2img"])
+    print(f"[{dt}] euler_ancestral_cfgpp: img2img rel-L2 {r1:.3e}, txt2img {r2:.3e}")
+    assert r1 <= tol and r2 <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_hiresfix_chain(ldx, g, unet, dt, tol):
+    """pipeline.py:346-366 on device: bislerp x2 -> 10 steps euler_ancestral_cfgpp/normal, cfg 8, denoise 0.45."""
+    latent_upscale = ldx.latent_upscale
+    ks = ldx.sampling.KSampler(unet[dt])
+    up = latent_upscale(torch.from_numpy(g["hf_base"]).cuda(), 16 * 8 * 2, 16 * 8 * 2)
+    ref_up = torch.from_numpy(g["hf_up"])           # synthetic-weight latents reach |x| ~ 4e2: bound relative to the scale
+    assert float((up.cpu() - ref_up).abs().max()) <= 2e-6 * float(ref_up.abs().max())
+    out = ks.sample(seed=77, steps=10, cfg=8, denoise=0.45, positive=torch.from_numpy(g["P"]), negative=torch.from_numpy(g["N"]),
+                    latent_image=up.cpu(), sampler_name="euler_ancestral_cfgpp", scheduler="normal")
+    r = _rel(out, g["hf_out"])
+    print(f"[{dt}] HiresFix chain: rel-L2 {r:.3e}")
+    assert r <= tol

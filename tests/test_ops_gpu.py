@@ -126,6 +126,31 @@ def test_conv3x3(L, ldx, dt, case):
     _check(Y, ref, dt, what=f"conv {case}")
 
 
+def test_conv3x3_image_over_2gib(L, ldx):
+    """VAE decode at 2048^2 (config 5): one NHWC input image of 2048*2048*256 bf16 = 2 GiB.  The conv loader's buffer
+    window is per tile, so rows whose byte offset exceeds 2^31 must still be right: check bands at the top, around the
+    2 GiB mark and at the bottom against torch's conv on the same rows."""
+    td, code = DT["bf16"]
+    B, H, W, Cin, Cout = 1, 2048, 2048, 256, 64
+    g = torch.Generator(device="cuda").manual_seed(5)
+    X = torch.randn(B, H, W, Cin, device="cuda", generator=g, dtype=torch.float32).to(td)
+    Wt = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)).to(td)
+    Wp = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    Y = torch.zeros(B * H * W, Cout, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_conv3x3(_p(X), Cin, _p(Wp), B, H, W, Cin, Cout, 1, H, W, 0, _p(bias), None, 0, None, 0,
+                                   _p(Y), Cout, code, _st()), "conv")
+    torch.cuda.synchronize()
+    Y = Y.view(H, W, Cout)
+    for r0, r1 in ((0, 4), (1022, 1027), (1530, 1534), (2044, 2048)):
+        lo, hi = max(r0 - 1, 0), min(r1 + 1, H)
+        band = X[0, lo:hi].float().permute(2, 0, 1)[None]                        # [1, Cin, rows, W]
+        band = F.pad(band, (0, 0, 1 if r0 == 0 else 0, 1 if r1 == H else 0))
+        ref = F.conv2d(F.pad(band, (1, 1, 0, 0)), Wt.float(), bias)[0].permute(1, 2, 0)
+        assert ref.shape[0] == r1 - r0
+        _check(Y[r0:r1].reshape(-1, Cout), ref.reshape(-1, Cout), "bf16", what=f"conv rows {r0}:{r1}")
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("B,HW,C,extra,silu,eps", [(2, 256, 64, 0, 1, 1e-5), (2, 1024, 320, 64, 1, 1e-5), (1, 300, 2560, 0, 0, 1e-6),
                                                    (2, 4096, 192, 0, 1, 1e-5), (1, 16384, 320, 0, 1, 1e-5), (3, 77, 1920, 0, 1, 1e-5)])
