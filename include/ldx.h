@@ -123,7 +123,8 @@ int ldx_unet_forward(ldx_engine* e, const float* x_nchw, const float* timesteps,
 int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes);
 /* Per-kernel-class timing of subsequent eager forwards with HIP events recorded on the launch stream
  * (used by bench.py for the roofline line).  ldx_profile_report writes a JSON object
- * {"<kernel>": {"count", "ms", "flops", "bytes"}, ...} (algorithmic flops/bytes, summed) into buf. */
+ * {"<kernel>": {"count", "ms", "flops", "bytes"}, ...} (algorithmic flops/bytes, summed) into buf.
+ * enable = 2 keys the report by kernel class *and* op shape (tuning aid). */
 int ldx_profile(ldx_engine* e, int enable, int reset);
 int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap);
 /* Capture the planned forward into a hipGraph for replay (0 = eager launches). */

@@ -156,6 +156,7 @@ int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* ar
 int ldx_profile(ldx_engine* e, int enable, int reset) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     e->impl->profiling = enable != 0;
+    e->impl->prof_detail = enable == 2;
     if (reset) e->impl->prof.clear();
     return LDX_OK;
 }

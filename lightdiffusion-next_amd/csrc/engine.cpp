@@ -782,6 +782,14 @@ int Engine::exec_ops(hipStream_t ls) {
             HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
             const Op& o = ops[i];
             std::string key = o.klabel[0] ? o.klabel : o.name;
+            if (prof_detail) {
+                char sh[96] = "";
+                if (o.kind == OP_GEMM) snprintf(sh, sizeof(sh), " M%d N%d K%d sk%d%s", o.g.M, o.g.N, o.g.K, o.g.splitk, o.g.geglu ? " geglu" : "");
+                else if (o.kind == OP_ATTN) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D%d", o.at.B, o.at.H, o.at.Nq, o.at.Mk, o.at.D);
+                else if (o.kind == OP_GN) snprintf(sh, sizeof(sh), " B%d HW%d C%d", o.gn.B, o.gn.HW, o.gn.C);
+                else if (o.kind == OP_LN) snprintf(sh, sizeof(sh), " R%d C%d", o.ln.rows, o.ln.C);
+                key += sh;
+            }
             ProfEntry& pe = prof[key];
             pe.count += 1; pe.ms += ms; pe.flops += o.flops; pe.bytes += o.bytes;
         }

@@ -89,7 +89,7 @@ public:
     int plan(int B2, int h, int w, int Mc);
     int64_t n_launches() const;
     // per-kernel-class HIP-event profile of subsequent forwards (bench.py roofline leg)
-    bool profiling = false;
+    bool profiling = false, prof_detail = false;   // detail: key the report by op shape as well
     std::map<std::string, ProfEntry> prof;
     std::string profile_json() const;
 

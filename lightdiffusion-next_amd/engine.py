@@ -112,7 +112,7 @@ class UNetEngine:
 
     def profile_report(self) -> dict:
         import json
-        buf = C.create_string_buffer(1 << 16)
+        buf = C.create_string_buffer(1 << 18)
         lib.check(self._lib.ldx_profile_report(self._h, buf, len(buf)), "ldx_profile_report")
         return json.loads(buf.value.decode())
 
