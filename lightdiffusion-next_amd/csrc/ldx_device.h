@@ -82,15 +82,47 @@ __device__ __forceinline__ float gelu_tanh_f(float x) {
     return x / (1.0f + __expf(-2.0f * u));
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across rows) instead of
+// __shfl_xor's ds_bpermute round trips through the LDS pipe.  All lanes of the wave must be active.
+template <int CTRL> __device__ __forceinline__ float dpp_f(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror: the other quad of the 8-lane half
+    v += dpp_f<0x140>(v);     // row_mirror: the other half of the 16-lane row
     return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+__device__ __forceinline__ float row16_max(float v) {
+    v = fmaxf(v, dpp_f<0xB1>(v));
+    v = fmaxf(v, dpp_f<0x4E>(v));
+    v = fmaxf(v, dpp_f<0x141>(v));
+    v = fmaxf(v, dpp_f<0x140>(v));
     return v;
+}
+__device__ __forceinline__ float xrow16_sum(float v) {    // + lane ^ 16
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+__device__ __forceinline__ float xrow32_sum(float v) {    // + lane ^ 32
+    auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return __uint_as_float(a[0]) + __uint_as_float(a[1]);
+}
+// sum over groups of LPR consecutive lanes (16, 32 or 64); every lane of the group gets the total
+template <int LPR> __device__ __forceinline__ float group_sum(float v) {
+    v = row16_sum(v);
+    if (LPR >= 32) v = xrow16_sum(v);
+    if (LPR >= 64) v = xrow32_sum(v);
+    return v;
+}
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) {
+    v = row16_max(v);
+    auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+    auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+    return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
 }
 
 // XCD-aware block remap (8 XCDs, block b is dispatched to XCD b % 8): give each XCD a contiguous

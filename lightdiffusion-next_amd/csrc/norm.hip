@@ -172,13 +172,16 @@ void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// LayerNorm: one wave per row, row held in registers (C <= 512 * NCH), two-pass mean / variance.
+// LayerNorm: LPR lanes per row (16 / 32 / 64, so that a narrow row does not leave most of the wave idle and a
+// wave keeps several rows' loads in flight), row held in registers (C <= 8 * LPR * NCH), two-pass mean / variance.
 // Optional affine (gamma/beta) and optional per-batch adaLN modulation (Flux).
-template <typename T, int NCH>
+template <typename T, int LPR, int NCH>
 __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
-    const int lane = threadIdx.x & 63;
-    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= p.rows) return;
+    constexpr int RPW = 64 / LPR;                     // rows per wave
+    const int lane = threadIdx.x & 63, sub = lane % LPR;
+    const long row_raw = ((long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + lane / LPR;
+    const bool live = row_raw < p.rows;               // dead rows compute on the last row (all lanes stay active for the DPP reductions)
+    const long row = live ? row_raw : p.rows - 1;
     const int nch = p.C >> 3;
     const T* __restrict__ x = (const T*)p.X + row * p.ldx;
     T* __restrict__ y = (T*)p.Y + row * p.ldy;
@@ -186,29 +189,29 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
+        const int ch = sub + LPR * i;
         if (ch < nch) {
             unpack8<T>(*(const uint4*)(x + ch * 8), f[i]);
 #pragma unroll
             for (int e = 0; e < 8; ++e) sum += f[i][e];
         }
     }
-    const float mean = wave_sum(sum) / (float)p.C;
+    const float mean = group_sum<LPR>(sum) / (float)p.C;
     float vs = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
+        const int ch = sub + LPR * i;
         if (ch < nch) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) { const float d = f[i][e] - mean; vs = fmaf(d, d, vs); }
         }
     }
-    const float rstd = rsqrtf(wave_sum(vs) / (float)p.C + p.eps);
+    const float rstd = rsqrtf(group_sum<LPR>(vs) / (float)p.C + p.eps);
     const long mb = p.scale ? (row / p.rows_per_batch) * (long)p.mod_ld : 0;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
-        const int ch = lane + 64 * i;
-        if (ch < nch) {
+        const int ch = sub + LPR * i;
+        if (ch < nch && live) {
             float o[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -223,12 +226,23 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
     }
 }
 
+template <typename T>
+static void launch_ln_t(const LayerNormArgs& a, hipStream_t s) {
+    const int nch = a.C >> 3;
+    dim3 block(256);
+#define LDX_LN(LPR, NCH) do { const int rpb = 4 * (64 / LPR); \
+        hipLaunchKernelGGL((ln_kernel<T, LPR, NCH>), dim3((unsigned)((a.rows + rpb - 1) / rpb)), block, 0, s, a); } while (0)
+    if (nch <= 48) LDX_LN(16, 3);              // C <= 384  (SD1.5 level 0: 320)
+    else if (nch <= 96) LDX_LN(32, 3);         // C <= 768  (640, CLIP 768)
+    else if (nch <= 192) LDX_LN(64, 3);        // C <= 1536 (1280)
+    else if (nch <= 256) LDX_LN(64, 4);        // C <= 2048
+    else LDX_LN(64, 6);                        // C <= 3072 (Flux)
+#undef LDX_LN
+}
+
 void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s) {
     if (a.rows <= 0) return;
-    dim3 grid((a.rows + 3) / 4), block(256);
-    const bool big = a.C > 2048;
-    if (dt == DT_BF16) { if (big) hipLaunchKernelGGL((ln_kernel<__bf16, 6>), grid, block, 0, s, a); else hipLaunchKernelGGL((ln_kernel<__bf16, 4>), grid, block, 0, s, a); }
-    else { if (big) hipLaunchKernelGGL((ln_kernel<_Float16, 6>), grid, block, 0, s, a); else hipLaunchKernelGGL((ln_kernel<_Float16, 4>), grid, block, 0, s, a); }
+    if (dt == DT_BF16) launch_ln_t<__bf16>(a, s); else launch_ln_t<_Float16>(a, s);
 }
 
 // ------------------------------------------------------------------------------------------
