@@ -13,6 +13,7 @@
 // both the ds_write_b128 staging and the ds_read_b128 fragment reads bank-conflict free.
 // The MFMA is issued as D = W_frag x A_frag so each lane ends up with 4 consecutive output
 // channels of one output row -> 8-byte coalesced epilogue stores into the NHWC activation.
+#include <stdlib.h>
 #include "ldx_device.h"
 #include "ldx_kernels.h"
 
@@ -330,7 +331,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 struct TileSel { int bm, bn; };
 static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     if (geglu) return {128, 128};
-    const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+    int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
+    // wave quantisation: 257..511 tiles of 128x128 put two workgroups on some CUs and one on the rest (the launch takes as
+    // long as the doubly-loaded CUs); if 128x160 tiles fit one per CU, every CU runs a single, 1.25x larger tile instead
+    if (bn == 128 && N % 160 == 0 && splitk <= 1 && !getenv("LDX_NO_TILE160")) {
+        const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t160 = (long)((M + 127) / 128) * (N / 160);
+        if (t128 > 256 && t128 < 512 && t160 <= 256) bn = 160;
+    }
     const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn) * (splitk > 1 ? splitk : 1);
     // < 0.8 of one round of 2 workgroups x 256 CUs and a short K loop (latency-bound): go small.
     // Long-K problems (3x3 convs) keep the big tile: measured 112 us (128x128) vs 125 us (64x64) at 64^2, 640->640;
