@@ -74,6 +74,17 @@ typedef struct ldx_clip_config {
     int32_t vocab_size;             /* 49408 */
 } ldx_clip_config;
 
+/* T5 encoder — src/clip/clip/t5_config_xxl.json as read by T5 (src/clip/FluxClip.py:476-519): gated tanh-GELU FF,
+ * RMS T5LayerNorm (eps 1e-6), relative-position bias from block 0 shared by every block, inner_dim = d_model. */
+typedef struct ldx_t5_config {
+    int32_t compute_dtype;
+    int32_t d_model;               /* 4096 ; multiple of 64 */
+    int32_t d_ff;                  /* 10240 ; multiple of 64 */
+    int32_t num_layers;            /* 24 */
+    int32_t num_heads;             /* 64 ; head dim = d_model / num_heads, multiple of 8, <= 160 */
+    int32_t vocab_size;            /* 32128 */
+} ldx_t5_config;
+
 /* Flux DiT — FluxParams (src/BlackForest/Flux.py:293-306); flux-dev: 16, 768, 4096, 3072, 4.0, 24, 19, 38,
  * axes [16,56,56], theta 10000, qkv_bias 1, guidance_embed 1. */
 typedef struct ldx_flux_config {
@@ -150,6 +161,18 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
 
+/* ---- T5-XXL text encoder (Flux conditioning) ---------------------------------------------------- */
+/* Keys: T5's state dict ("shared.weight", "encoder.block.0.layer.0.SelfAttention.q.weight", ...,
+ * "encoder.block.0.layer.1.DenseReluDense.wi_0.weight", "encoder.final_layer_norm.weight").  The relative-attention
+ * embedding (encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight) stays with the host, which builds
+ * the bias table exactly as T5Attention.compute_bias does (FluxClip.py:150-243). */
+int ldx_t5_create(const ldx_t5_config* cfg, int device, ldx_engine** out);
+/* T5.forward -> T5Stack.forward (FluxClip.py:441-519): ids [B][L] int32; bias = relative-position bias fp32
+ * [num_heads][L][Lp], Lp = L rounded up to 64 (padding ignored), shared by the batch and by all blocks; no padding mask;
+ * attention is unscaled (the reference pre-multiplies k by sqrt(d) to cancel SDPA's scale, :265-268).
+ * out = final_layer_norm(x_L) [B][L][d_model] fp32. */
+int ldx_t5_encode(ldx_engine* e, const int32_t* ids, int B, int L, const float* bias, float* out, void* stream);
+
 /* ---- Flux DiT ------------------------------------------------------------------------------ */
 /* Keys for ldx_load_tensor: Flux3's state dict ("img_in.weight", "double_blocks.0.img_mod.lin.weight", ...). */
 int ldx_flux_create(const ldx_flux_config* cfg, int device, ldx_engine** out);
@@ -195,6 +218,10 @@ int ldx_op_layernorm(const void* X, int ldx, void* Y, int ldy, int rows, int C, 
                      const float* gamma, const float* beta, int dtype, void* stream);
 int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                      int B, int H, int Nq, int Mk, int D, float scale, int causal, int dtype, void* stream);
+/* attention with an additive fp32 score bias [H][>= Nq][bias_ld] (bias_ld >= Mk rounded up to 64), added before the scale */
+int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
+                          int B, int H, int Nq, int Mk, int D, float scale, const float* bias, int bias_ld,
+                          int64_t bias_head_stride, int dtype, void* stream);
 int ldx_op_skinny(const float* x, int ldx, const void* W, const float* bias, float* out, int ldo,
                   int M, int N, int K, int in_act, int out_act, int dtype, void* stream);
 

@@ -193,6 +193,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
         }
         __builtin_amdgcn_s_setprio(0);
 
+        // ---- additive score bias (T5 relative positions): lane holds q = l15, keys 16t + 4*g4 + 0..3 ----
+        if (p.bias) {
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) {
+                const int q = min(q0 + qt * 16 + l15, p.Nq - 1);
+                const float* bp = p.bias + (long)h * p.bias_hs + (long)q * p.bias_ld + kv0 + g4 * 4;
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const float4 bv = *(const float4*)(bp + t * 16);
+                    s[qt][t][0] += bv.x; s[qt][t][1] += bv.y; s[qt][t][2] += bv.z; s[qt][t][3] += bv.w;
+                }
+            }
+        }
+
         // ---- masking (block-uniform fast path) ----
         const bool need_mask = (kv0 + AT_KV > p.Mk) || (p.causal && (kv0 + AT_KV - 1 > qblk * AT_QB));
         if (need_mask) {

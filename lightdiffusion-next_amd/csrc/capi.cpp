@@ -95,6 +95,21 @@ int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_l
     return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_t5_create(const ldx_t5_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_t5_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    *out = new ldx_engine{new Engine(*cfg, device)};
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_t5_encode(ldx_engine* e, const int32_t* ids, int B, int L, const float* bias, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_t5((const int*)ids, B, L, bias, out, (hipStream_t)stream);
+    GUARD_END
+}
 int ldx_flux_create(const ldx_flux_config* cfg, int device, ldx_engine** out) {
     GUARD_BEGIN
     if (!cfg || !out) { set_error("ldx_flux_create: null argument"); return LDX_EINVAL; }
@@ -129,6 +144,7 @@ int ldx_finalize(ldx_engine* e) {
     if (e->impl->kind == KIND_VAE) return e->impl->finalize_vae();
     if (e->impl->kind == KIND_CLIP) return e->impl->finalize_clip();
     if (e->impl->kind == KIND_FLUX) return e->impl->finalize_flux();
+    if (e->impl->kind == KIND_T5) return e->impl->finalize_t5();
     return e->impl->finalize();
     GUARD_END
 }
@@ -247,9 +263,18 @@ int ldx_op_layernorm(const void* X, int ldx_, void* Y, int ldy, int rows, int C,
 int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
                      float scale, int causal, int dtype, void* stream) {
     if (!Q || !K || !V || !O || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160)"); return LDX_EINVAL; }
-    AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal};
+    AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal, nullptr, 0, 0};
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention");
+}
+int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
+                          float scale, const float* bias, int bias_ld, int64_t bias_head_stride, int dtype, void* stream) {
+    if (!Q || !K || !V || !O || !bias || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0 || bias_ld % 4 ||
+        bias_ld < ((Mk + 63) / 64) * 64 || bias_head_stride % 4) {
+        set_error("ldx_op_attention_bias: bad argument (bias_ld >= Mk rounded up to 64, multiples of 4)"); return LDX_EINVAL; }
+    AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, 0, bias, bias_ld, (long)bias_head_stride};
+    launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_attention_bias");
 }
 int ldx_op_skinny(const float* x, int ldx_, const void* W, const float* bias, float* out, int ldo, int M, int N, int K, int in_act, int out_act, int dtype, void* stream) {
     if (!x || !W || !out || K % 8) { set_error("ldx_op_skinny: bad argument"); return LDX_EINVAL; }

@@ -749,7 +749,10 @@ int Engine::exec_ops(hipStream_t ls) {
             case OP_GEMM: launch_gemm(o.g, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
-            case OP_ATTN: launch_attention(o.at, dt, ls); break;
+            case OP_ATTN:
+                if (o.i3 == 1) { AttnArgs a = o.at; a.bias = b_bias; launch_attention(a, dt, ls); }      // per-call bias table (T5)
+                else launch_attention(o.at, dt, ls);
+                break;
             case OP_FINISH: {
                 FinishArgs f{};
                 f.eps = d_eps; f.ld = cfg.out_channels; f.x = b_den ? b_x : nullptr; f.sigma = b_s; f.out = b_out;
@@ -759,7 +762,7 @@ int Engine::exec_ops(hipStream_t ls) {
             case OP_VAEPREP: launch_vae_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, vae_pq, vae_pq ? vae_pq + o.i1 * o.i1 : nullptr, dt, ls); break;
             case OP_SOFTMAX: launch_softmax_rows(o.p1, o.i0, o.i1, o.i2, o.f0, dt, ls); break;
             case OP_CLAMP: launch_clamp01((const float*)o.p0, b_out, (size_t)o.i0, ls); break;
-            case OP_EMBED: launch_clip_embed(b_ids, clip_tok, clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
+            case OP_EMBED: launch_clip_embed(b_ids, kind == KIND_T5 ? t5_tok : clip_tok, kind == KIND_T5 ? nullptr : clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
             case OP_CVT_OUT: if ((o.i3 ? b_out2 : b_out) != nullptr) launch_t_to_f32(o.p0, o.i3 ? b_out2 : b_out, (size_t)o.i0, dt, ls); break;
             case OP_PIXPREP: launch_pixels_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
             case OP_MOMENTS: launch_mix_nhwc_to_nchw((const float*)o.p0, o.i1, b_out, o.i0, o.i1, o.i2, enc_qc, enc_qc ? enc_qc + o.i1 * o.i1 : nullptr, ls); break;

@@ -39,7 +39,7 @@ enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FIN
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS,
               OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G };
-enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3 };
+enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4 };
 struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp;
@@ -54,6 +54,7 @@ struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
 struct VaeAttnW { NormW norm; LinearW q, k, v, proj; };
 struct ClipLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
+struct T5LayerW { NormW ln1, ln2; LinearW qkv, o, wi, wo; };
 struct FluxStreamW { LinearW qkv, proj, mlp0, mlp2; float* qs = nullptr; float* ks = nullptr; int mod_off = 0; };
 struct FluxDoubleW { FluxStreamW img, txt; };
 struct FluxSingleW { LinearW lin1_qkv, lin1_mlp, lin2; float* qs = nullptr; float* ks = nullptr; int mod_off = 0; };
@@ -64,6 +65,12 @@ public:
     Engine(const ldx_vae_config& c, int dev);
     Engine(const ldx_clip_config& c, int dev);
     Engine(const ldx_flux_config& c, int dev);
+    Engine(const ldx_t5_config& c, int dev);
+    ldx_t5_config tcfg{};
+    std::vector<T5LayerW> t5_layers; NormW t5_final_ln; float* t5_tok = nullptr; const float* b_bias = nullptr;
+    int finalize_t5();
+    int plan_t5(int B, int L);
+    int run_t5(const int* ids, int B, int L, const float* bias, float* out, hipStream_t st);
     ldx_flux_config fcfg{};
     int finalize_flux();
     int plan_flux(int B, int h, int w, int Lt);

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 }
                 float v[4];
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = a[r] * gelu_erf_f(g[r]);
+                for (int r = 0; r < 4; ++r) v[r] = a[r] * (p.geglu == 2 ? gelu_tanh_f(g[r]) : gelu_erf_f(g[r]));
                 if (Cp) *(uint2*)(Cp + (long)m * p.ldc + no) = pack4<T>(v[0], v[1], v[2], v[3]);
                 if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
             }

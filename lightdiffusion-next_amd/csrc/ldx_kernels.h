@@ -33,7 +33,7 @@ struct GemmArgs {
     int pad0;                      // conv: 1 -> no top/left padding (VAE Downsample: F.pad (0,1,0,1) + stride-2 conv, VariationalAE.py:224-254)
     const float* bias;             // [N] or null
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
-    int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2
+    int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2: a * gelu_erf(g); 2: a * gelu_tanh(g)
     int act;                       // 0 none, 1 quick-GELU x*sigmoid(1.702x) after bias (CLIP MLP, clip/Clip.py:74-77),
                                    // 2 tanh-GELU (Flux MLPs, BlackForest/Flux.py:279,388)
     const float* gate; int gate_ld; // per-batch channel gate (Flux adaLN): v *= gate[(m / rows_per_batch)][n] before + R
@@ -64,6 +64,9 @@ struct AttnArgs {
     const void* Q; int ldq; const void* K; int ldk; const void* V; int ldv;
     void* O; int ldo;
     int B, H, Nq, Mk, D; float scale; int causal;
+    // optional additive score bias (T5 relative-position bias): fp32 [H][>= Nq][bias_ld], bias_ld = Mk rounded up to 64,
+    // shared by the batch, added to q.k BEFORE the scale (pass bias / scale); padded entries are ignored
+    const float* bias; int bias_ld; long bias_hs;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
 
@@ -86,6 +89,7 @@ struct LayerNormArgs {
     const void* X; int ldx; void* Y; int ldy; int rows, C; float eps;
     const float* gamma; const float* beta;
     const float* scale; const float* shift; int mod_ld; int rows_per_batch;
+    int rms;                       // 1: T5LayerNorm (no mean subtraction, no beta): x * rsqrt(mean(x^2) + eps) * gamma
 };
 void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s);
 

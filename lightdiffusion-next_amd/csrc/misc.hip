@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const f
         id = max(0, min(id, vocab - 1));
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = tok[(long)id * C + ch * 8 + e] + pos[(long)t * C + ch * 8 + e];
+        for (int e = 0; e < 8; ++e) f[e] = tok[(long)id * C + ch * 8 + e] + (pos ? pos[(long)t * C + ch * 8 + e] : 0.f);
         *(uint4*)(out + bt * C + ch * 8) = pack8<T>(f);
     }
 }

@@ -196,7 +196,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
             for (int e = 0; e < 8; ++e) sum += f[i][e];
         }
     }
-    const float mean = group_sum<LPR>(sum) / (float)p.C;
+    const float mean = p.rms ? 0.f : group_sum<LPR>(sum) / (float)p.C;
     float vs = 0.f;
 #pragma unroll
     for (int i = 0; i < NCH; ++i) {
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
             for (int e = 0; e < 8; ++e) {
                 const int c = ch * 8 + e;
                 float v = (f[i][e] - mean) * rstd;
-                if (p.gamma) v = v * p.gamma[c] + p.beta[c];
+                if (p.gamma) v = v * p.gamma[c] + (p.beta ? p.beta[c] : 0.f);
                 if (p.scale) v = (1.0f + p.scale[mb + c]) * v + p.shift[mb + c];
                 o[e] = v;
             }
@@ -236,7 +236,8 @@ static void launch_ln_t(const LayerNormArgs& a, hipStream_t s) {
     else if (nch <= 96) LDX_LN(32, 3);         // C <= 768  (640, CLIP 768)
     else if (nch <= 192) LDX_LN(64, 3);        // C <= 1536 (1280)
     else if (nch <= 256) LDX_LN(64, 4);        // C <= 2048
-    else LDX_LN(64, 6);                        // C <= 3072 (Flux)
+    else if (nch <= 384) LDX_LN(64, 6);        // C <= 3072 (Flux)
+    else LDX_LN(64, 8);                        // C <= 4096 (T5-XXL)
 #undef LDX_LN
 }
 

@@ -10,6 +10,7 @@ import math
 import torch
 
 from . import lib
+from .weights import T5Config  # noqa: F401
 from .weights import UNetConfig, VAEConfig, CLIPConfig, FluxConfig
 
 
@@ -284,6 +285,99 @@ class CLIPTextEngine:
         cond = out[-1:] if not output else torch.cat(output, dim=-2)
         return cond, pooled[0:1].float().cpu()
 
+    close = UNetEngine.close
+    __del__ = UNetEngine.__del__
+
+
+def t5_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
+    """T5Attention._relative_position_bucket, bidirectional (src/clip/FluxClip.py:152-205) — same torch ops in the same
+    order, so bucket boundaries (float32 log) agree bit for bit with the reference."""
+    import math as _m
+    num_buckets //= 2
+    relative_buckets = (relative_position > 0).to(torch.long) * num_buckets
+    relative_position = torch.abs(relative_position)
+    max_exact = num_buckets // 2
+    is_small = relative_position < max_exact
+    large = max_exact + (torch.log(relative_position.float() / max_exact) / _m.log(max_distance / max_exact)
+                         * (num_buckets - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return relative_buckets + torch.where(is_small, relative_position, large)
+
+
+def t5_bias_table(rel_bias_weight, length: int, num_buckets=32, max_distance=128):
+    """T5Attention.compute_bias (FluxClip.py:207-243) -> fp32 [H][L][Lp], Lp = L rounded up to 64 (zero padded): the
+    layout ldx_t5_encode reads."""
+    ctx = torch.arange(length, dtype=torch.long)[:, None]
+    mem = torch.arange(length, dtype=torch.long)[None, :]
+    bucket = t5_relative_position_bucket(mem - ctx, num_buckets, max_distance)           # [L, L]
+    vals = rel_bias_weight.float()[bucket].permute(2, 0, 1).contiguous()                 # [H, L, L]
+    lp = (length + 63) // 64 * 64
+    out = torch.zeros((vals.shape[0], length, lp), dtype=torch.float32)
+    out[:, :, :length] = vals
+    return out
+
+
+class T5Engine:
+    """T5.forward (src/clip/FluxClip.py:441-519): token ids -> final_layer_norm(encoder output), fp32.  Host side keeps
+    the 32 x heads relative-attention embedding and builds the bias table per sequence length (cached)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0, dtype: str = "bf16"):
+        self._lib = lib.load()
+        self._h = C.c_void_p()
+        self.cfg, self.device = cfg, torch.device("cuda", device)
+        c = lib.ldx_t5_config()
+        c.compute_dtype = {"bf16": lib.LDX_BF16, "f16": lib.LDX_F16, "fp16": lib.LDX_F16}[dtype]
+        c.d_model, c.d_ff, c.num_layers, c.num_heads, c.vocab_size = cfg.d_model, cfg.d_ff, cfg.num_layers, cfg.num_heads, cfg.vocab_size
+        lib.check(self._lib.ldx_t5_create(C.byref(c), device, C.byref(self._h)), "ldx_t5_create")
+        rk = "encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight"
+        self._rel = state_dict[rk].float().cpu()
+        _load_state_dict(self._lib, self._h, {k: v for k, v in state_dict.items() if k != rk}, strip=("t5xxl.transformer.",))
+        lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+        self._bias = {}
+
+    def bias(self, length: int):
+        if length not in self._bias:
+            self._bias[length] = t5_bias_table(self._rel, length, self.cfg.num_buckets, self.cfg.max_distance).to(self.device)
+        return self._bias[length]
+
+    def forward(self, tokens):
+        """tokens: int tensor [B][L] -> [B, L, d_model] fp32."""
+        ids = tokens.to(self.device, torch.int32).contiguous()
+        b, l = ids.shape
+        out = torch.empty((b, l, self.cfg.d_model), device=self.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_t5_encode(self._h, lib.ptr(ids), b, l, lib.ptr(self.bias(l)), lib.ptr(out), lib.current_stream_ptr()),
+                  "ldx_t5_encode")
+        return out
+
+    def encode_token_weights(self, token_weight_pairs):
+        """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) as T5XXLModel runs it (FluxClip.py:521-545):
+        special tokens {end: 1, pad: 0}, layer "last", no pooled output.  Returns (cond [1, sum L, d_model], None)."""
+        to_encode, has_weights, max_len = [], False, 0
+        for x in token_weight_pairs:
+            toks = [a[0] for a in x]
+            max_len = max(max_len, len(toks))
+            has_weights = has_weights or not all(a[1] == 1.0 for a in x)
+            to_encode.append(toks)
+        sections = len(to_encode)
+        if has_weights or sections == 0:
+            to_encode.append([1] + [0] * (max_len - 1))                      # gen_empty_tokens (SDClip.py:10-22)
+        out = self.forward(torch.tensor(to_encode, dtype=torch.int64)).float().cpu()
+        output = []
+        for k in range(sections):
+            z = out[k:k + 1].clone()
+            if has_weights:
+                z_empty = out[-1]
+                for j in range(z.shape[1]):
+                    wgt = token_weight_pairs[k][j][1]
+                    if wgt != 1.0:
+                        z[0][j] = (z[0][j] - z_empty[j]) * wgt + z_empty[j]
+            output.append(z)
+        cond = out[-1:] if not output else torch.cat(output, dim=-2)
+        return cond, None
+
+    profile = UNetEngine.profile
+    profile_report = UNetEngine.profile_report
+    plan_info = UNetEngine.plan_info
     close = UNetEngine.close
     __del__ = UNetEngine.__del__
 

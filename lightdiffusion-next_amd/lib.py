@@ -43,6 +43,11 @@ class ldx_clip_config(C.Structure):
                 ("intermediate_size", C.c_int32), ("max_positions", C.c_int32), ("vocab_size", C.c_int32)]
 
 
+class ldx_t5_config(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("d_model", C.c_int32), ("d_ff", C.c_int32), ("num_layers", C.c_int32),
+                ("num_heads", C.c_int32), ("vocab_size", C.c_int32)]
+
+
 class ldx_flux_config(C.Structure):
     _fields_ = [("compute_dtype", C.c_int32), ("in_channels", C.c_int32), ("vec_in_dim", C.c_int32), ("context_in_dim", C.c_int32),
                 ("hidden_size", C.c_int32), ("mlp_hidden", C.c_int32), ("num_heads", C.c_int32), ("depth", C.c_int32),
@@ -68,6 +73,8 @@ _SIGS = {
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldx_t5_create": (_i, [C.POINTER(ldx_t5_config), _i, C.POINTER(_vp)]),
+    "ldx_t5_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ldx_flux_create": (_i, [C.POINTER(ldx_flux_config), _i, C.POINTER(_vp)]),
     "ldx_flux_forward": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldx_sampler_step": (_i, [_i, _vp, _vp, _vp, _vp, _i64, _f, _f, _f, _vp]),
@@ -81,6 +88,7 @@ _SIGS = {
     "ldx_op_groupnorm_workspace_floats": (_i64, [_i, _i]),
     "ldx_op_layernorm": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "ldx_op_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
+    "ldx_op_attention_bias": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i64, _i, _vp]),
     "ldx_op_skinny": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
 EXPORTS = tuple(_SIGS)

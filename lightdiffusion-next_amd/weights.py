@@ -160,6 +160,9 @@ def synth_tensor(key: str, shape, seed: int, dtype=torch.float16) -> torch.Tenso
         for s in shape[1:]:
             fan_in *= s
         t = n / math.sqrt(max(fan_in, 1))
+        # T5 attention is unscaled (no 1/sqrt(d)): trained q/k projections are small; 0.4 ~ d^(-1/4) keeps the logits O(1)
+        if key.endswith("SelfAttention.q.weight") or key.endswith("SelfAttention.k.weight"):
+            t = 0.4 * t
     return t.to(dtype)
 
 
@@ -302,6 +305,46 @@ def clip_state_dict_spec(cfg: CLIPConfig):
                  (f"{p}.mlp.fc2.weight", (e, f)), (f"{p}.mlp.fc2.bias", (e,))]
     spec += [("final_layer_norm.weight", (e,)), ("final_layer_norm.bias", (e,))]
     spec += [("text_projection.weight", (e, e))]       # CLIPTextModel.text_projection (CLIPTextModel.py:126-128), no prefix
+    return spec
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
+class T5Config:
+    """src/clip/clip/t5_config_xxl.json as read by T5 (src/clip/FluxClip.py:476-519); defaults = T5-XXL encoder."""
+
+    d_model: int = 4096
+    d_ff: int = 10240
+    num_layers: int = 24
+    num_heads: int = 64
+    vocab_size: int = 32128
+    num_buckets: int = 32          # T5Attention.relative_attention_num_buckets (FluxClip.py:140)
+    max_distance: int = 128        # .relative_attention_max_distance (:141)
+
+    @staticmethod
+    def tiny() -> "T5Config":
+        return T5Config(d_model=128, d_ff=256, num_layers=3, num_heads=4, vocab_size=512)
+
+    def reference_dict(self) -> dict:
+        return {"d_ff": self.d_ff, "d_kv": self.d_model // self.num_heads, "d_model": self.d_model, "dense_act_fn": "gelu_pytorch_tanh",
+                "is_gated_act": True, "model_type": "t5", "num_heads": self.num_heads, "num_layers": self.num_layers,
+                "vocab_size": self.vocab_size}
+
+
+def t5_state_dict_spec(cfg: T5Config):
+    """T5's state dict in module order (FluxClip.py:386-519): encoder.block.N.layer.{0,1}.*, final norm, shared."""
+    e, f = cfg.d_model, cfg.d_ff
+    spec = []
+    for l in range(cfg.num_layers):
+        a, m = f"encoder.block.{l}.layer.0", f"encoder.block.{l}.layer.1"
+        for n in ("q", "k", "v", "o"):
+            spec += [(f"{a}.SelfAttention.{n}.weight", (e, e))]
+        if l == 0:
+            spec += [(f"{a}.SelfAttention.relative_attention_bias.weight", (cfg.num_buckets, cfg.num_heads))]
+        spec += [(f"{a}.layer_norm.weight", (e,)),
+                 (f"{m}.DenseReluDense.wi_0.weight", (f, e)), (f"{m}.DenseReluDense.wi_1.weight", (f, e)),
+                 (f"{m}.DenseReluDense.wo.weight", (e, f)), (f"{m}.layer_norm.weight", (e,))]
+    spec += [("encoder.final_layer_norm.weight", (e,)), ("shared.weight", (cfg.vocab_size, e))]
     return spec
 
 

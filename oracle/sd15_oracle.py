@@ -602,6 +602,74 @@ def clip_encode_token_weights(sd, cfg, token_weight_pairs, layer_idx=-2, special
 
 
 # ---------------------------------------------------------------------------------------------------
+# T5 encoder (src/clip/FluxClip.py): Flux's second text encoder
+def t5_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
+    """T5Attention._relative_position_bucket, bidirectional (FluxClip.py:152-205)."""
+    num_buckets //= 2
+    rb = (relative_position > 0).to(torch.long) * num_buckets
+    rp = torch.abs(relative_position)
+    max_exact = num_buckets // 2
+    is_small = rp < max_exact
+    large = max_exact + (torch.log(rp.float() / max_exact) / math.log(max_distance / max_exact) * (num_buckets - max_exact)).to(torch.long)
+    large = torch.min(large, torch.full_like(large, num_buckets - 1))
+    return rb + torch.where(is_small, rp, large)
+
+
+def t5_rms_norm(x, weight, eps=1e-6):
+    """T5LayerNorm.forward (FluxClip.py:565-582)."""
+    return weight * (x * torch.rsqrt(x.pow(2).mean(-1, keepdim=True) + eps))
+
+
+def t5_forward(sd, cfg, tokens):
+    """T5.forward -> T5Stack.forward (FluxClip.py:441-519): relative-position bias computed by block 0 and reused,
+    unscaled attention (k * sqrt(d) against SDPA's 1/sqrt(d), :265-268), gated tanh-GELU FF, final RMS norm."""
+    w = W(sd)
+    x = w("shared.weight")[tokens]
+    b, l, e = x.shape
+    h = cfg.num_heads
+    d = e // h
+    ctx = torch.arange(l, dtype=torch.long)[:, None]
+    mem = torch.arange(l, dtype=torch.long)[None, :]
+    bucket = t5_relative_position_bucket(mem - ctx, cfg.num_buckets, cfg.max_distance)
+    bias = w("encoder.block.0.layer.0.SelfAttention.relative_attention_bias.weight")[bucket].permute(2, 0, 1).unsqueeze(0)
+    for i in range(cfg.num_layers):
+        a, f = w.sub(f"encoder.block.{i}.layer.0."), w.sub(f"encoder.block.{i}.layer.1.")
+        n = t5_rms_norm(x, a("layer_norm.weight"))
+        q, k, v = (F.linear(n, a(f"SelfAttention.{t}.weight")).view(b, l, h, d).transpose(1, 2) for t in ("q", "k", "v"))
+        o = F.scaled_dot_product_attention(q, k * (d ** 0.5), v, attn_mask=bias, dropout_p=0.0, is_causal=False)
+        x = x + F.linear(o.transpose(1, 2).reshape(b, l, e), a("SelfAttention.o.weight"))
+        n = t5_rms_norm(x, f("layer_norm.weight"))
+        g = F.gelu(F.linear(n, f("DenseReluDense.wi_0.weight")), approximate="tanh") * F.linear(n, f("DenseReluDense.wi_1.weight"))
+        x = x + F.linear(g, f("DenseReluDense.wo.weight"))
+    return t5_rms_norm(x, w("encoder.final_layer_norm.weight"))
+
+
+def t5_encode_token_weights(sd, cfg, token_weight_pairs):
+    """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) with T5XXLModel's special tokens {end 1, pad 0}."""
+    to_encode, has_weights, max_len = [], False, 0
+    for x in token_weight_pairs:
+        toks = [a[0] for a in x]
+        max_len = max(max_len, len(toks))
+        has_weights = has_weights or not all(a[1] == 1.0 for a in x)
+        to_encode.append(toks)
+    sections = len(to_encode)
+    if has_weights or sections == 0:
+        to_encode.append([1] + [0] * (max_len - 1))
+    out = t5_forward(sd, cfg, torch.tensor(to_encode, dtype=torch.int64))
+    output = []
+    for k in range(sections):
+        z = out[k:k + 1].clone()
+        if has_weights:
+            z_empty = out[-1]
+            for j in range(z.shape[1]):
+                wgt = token_weight_pairs[k][j][1]
+                if wgt != 1.0:
+                    z[0][j] = (z[0][j] - z_empty[j]) * wgt + z_empty[j]
+        output.append(z)
+    return out[-1:] if not output else torch.cat(output, dim=-2)
+
+
+# ---------------------------------------------------------------------------------------------------
 # Flux DiT  (src/BlackForest/Flux.py)
 def flux_rope(pos, dim, theta):
     """rope() (Flux.py:36-70): [..., n] -> [..., n, dim/2, 2, 2] rotation matrices, fp64 frequencies."""
