@@ -51,6 +51,39 @@ class ModelSamplingDiscrete:
         return log_sigma.exp()
 
 
+def flux_time_shift(mu, sigma, t):
+    """sampling.flux_time_shift (sampling.py:158-169)."""
+    return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+
+class ModelSamplingFlux:
+    """sampling.ModelSamplingFlux + CONST (sampling.py:100-218): 10000-entry shifted sigma table, timestep(sigma) = sigma,
+    x0 = sigma*noise + (1-sigma)*latent.  Like the reference's class it has NO sigma_min, so the "normal" and "karras"
+    schedulers raise AttributeError for Flux exactly as they do there; "simple" and "beta" only read the table."""
+
+    def __init__(self, shift=1.15, timesteps=10000):
+        self.shift = shift
+        self.sigmas = self.sigma(torch.arange(1, timesteps + 1, 1) / timesteps)
+
+    @property
+    def sigma_max(self):
+        return self.sigmas[-1]
+
+    def timestep(self, sigma):
+        return sigma
+
+    def sigma(self, timestep):
+        return flux_time_shift(self.shift, 1.0, timestep)
+
+    @staticmethod
+    def noise_scaling(sigma, noise, latent_image):
+        return sigma * noise + (1.0 - sigma) * latent_image
+
+    @staticmethod
+    def inverse_noise_scaling(sigma, latent):
+        return latent / (1.0 - sigma)
+
+
 def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
     ramp = torch.linspace(0, 1, n)
     min_inv_rho = sigma_min ** (1 / rho)
@@ -311,6 +344,41 @@ def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_s
     return x
 
 
+def _dy_step_cfgpp(x, model, sigma_next, sigma_hat, current_cfg):
+    """samplers.dy_sampling_step_cfg_pp (samplers.py:362-467): pixel (1,1) of every 2x2 block -> half-resolution image c,
+    model at sigma_hat (the step's old sigma), a second CFG of strength current_cfg on top of the guider's (here the hook
+    does see uncond_denoised), Euler update of c to sigma_next, scatter back.  The strided gather / scatter are torch
+    slice copies on the device (data movement only); the arithmetic is ldx_sampler_step."""
+    m, n = x.shape[2] // 2, x.shape[3] // 2
+    c = x[:, :, 1:2 * m:2, 1:2 * n:2].contiguous()
+    du, dc = model(c, sigma_hat)
+    d = torch.empty_like(c)
+    _step(2, c, du, dc, model.cfg, 0.0, 0.0, denoised_out=d)                  # guider's CFG: denoised
+    _step(0, c, du, d, current_cfg, sigma_hat, sigma_next - sigma_hat)        # uncond + (denoised - uncond) * current_cfg, Euler
+    x[:, :, 1:2 * m:2, 1:2 * n:2] = c
+    return x
+
+
+@torch.no_grad()
+def sample_euler_cfgpp(model, x, sigmas, cfg_scale=7.5, cfg_min=1.0, s_extra_steps=True, trace=None):
+    """samplers.sample_euler_dy_cfg_pp (samplers.py:470-609) with its defaults.  Main step = Euler on the guider's CFG
+    output (the CFG++ momentum branch is dead code, SURVEY.md Appendix A-2); after steps 2 and 3 (i // 2 == 1) the dy
+    extra step runs.  `model` must evaluate both branches (disable_cfg1_optimization, samplers.py:517-520)."""
+    n_steps = len(sigmas) - 1
+    for i in range(n_steps):
+        current_cfg = cfg_scale + (cfg_min - cfg_scale) * (i / n_steps)
+        sigma_hat = sigmas[i]
+        du, dc = model(x, sigma_hat)
+        if trace is not None:
+            trace.append(tuple(x.shape[-2:]))
+        _step(0, x, du, dc, model.cfg, sigma_hat, sigmas[i + 1] - sigma_hat)
+        if s_extra_steps and sigmas[i + 1] > 0 and i // 2 == 1:
+            if trace is not None:
+                trace.append((x.shape[-2] // 2, x.shape[-1] // 2))
+            x = _dy_step_cfgpp(x, model, sigmas[i + 1], sigma_hat, current_cfg)
+    return x
+
+
 _MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -320,8 +388,10 @@ def _resolve_sampler(sampler_name):
         return sample_dpmpp_2m_cfgpp, True
     if sampler_name == "euler_ancestral_cfgpp":
         return sample_euler_ancestral_cfgpp, True
-    if sampler_name in ("dpmpp_sde_cfgpp", "euler_cfgpp"):
-        raise NotImplementedError(f"sampler '{sampler_name}' (Brownian-tree noise / dy extra steps) is a next row (SURVEY §8 a5)")
+    if sampler_name == "euler_cfgpp":
+        return sample_euler_cfgpp, True
+    if sampler_name == "dpmpp_sde_cfgpp":
+        raise NotImplementedError(f"sampler '{sampler_name}' (Brownian-tree noise, torchsde) is a next row (SURVEY §8 a5)")
     return sample_euler, False
 
 
@@ -364,3 +434,71 @@ class KSampler:
         model = CFGDenoiser(self.engine, positive, negative, cfg, b, h, w, disable_cfg1_optimization=disable_cfg1)
         x = fn(model, x, sigmas, trace=trace, **extra)
         return x / 0.18215                                         # process_latent_out (CFG.py:294)
+
+
+# ------------------------------------------------------------------------------------------------------
+# Flux sampling path: KSampler.sample(flux=True), pipeline.py:237-262
+FLUX_LATENT_SCALE, FLUX_LATENT_SHIFT = 0.3611, 0.1159          # Latent.Flux1 (Latent.py:114-161)
+
+
+class FluxCFGDenoiser:
+    """CFGGuider.predict_noise for Flux2 (CFG.py:86-234; Flux2.extra_conds, Flux.py:800-815): conditioning = T5 context,
+    pooled CLIP vector (y) and the guidance scalar; batch order [uncond x B ; cond x B]."""
+
+    def __init__(self, engine, positive, negative, cfg, guidance, batch, disable_cfg1_optimization=False):
+        self.engine, self.cfg = engine, float(cfg)
+        dev = engine.device
+        self.skip_uncond = math.isclose(self.cfg, 1.0) and not disable_cfg1_optimization
+        (pc, py), (nc, ny) = positive, negative
+        f = lambda t: t.to(dev, torch.float32)          # noqa: E731
+        pc, py = f(pc).expand(batch, -1, -1), f(py).expand(batch, -1)
+        if self.skip_uncond:
+            self.ctx, self.y, self.nb = pc.contiguous(), py.contiguous(), batch
+        else:
+            nc, ny = f(nc).expand(batch, -1, -1), f(ny).expand(batch, -1)
+            nc, pc = _lcm_pad_contexts([nc, pc])
+            self.ctx, self.y, self.nb = torch.cat([nc, pc]).contiguous(), torch.cat([ny, py]).contiguous(), 2 * batch
+        self.guidance = torch.full((self.nb,), float(guidance), device=dev, dtype=torch.float32)
+        self.batch = batch
+
+    def __call__(self, x, sigma):
+        b = self.batch
+        xin = x if self.skip_uncond else torch.cat([x, x])
+        sig = torch.full((self.nb,), float(sigma), device=x.device, dtype=torch.float32)
+        out = self.engine.denoise(xin.contiguous(), sig, self.ctx, self.y, self.guidance)
+        if self.skip_uncond:
+            return out, out
+        return out[:b], out[b:]
+
+
+class FluxKSampler:
+    """KSampler.sample(flux=True) -> CFGGuider.sample -> KSAMPLER.sample (sampling.py:444-498, 773-1233; CFG.py:236-357) for
+    one positive and one negative (ctx, pooled) pair."""
+
+    def __init__(self, engine, shift=1.15):
+        self.engine = engine
+        self.model_sampling = ModelSamplingFlux(shift)
+
+    def sample(self, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent_image, guidance=3.0, denoise=1.0,
+               enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3, multiscale_fullres_end=8,
+               multiscale_intermittent_fullres=False, noise=None, trace=None):
+        ms = self.model_sampling
+        denoise = denoise or 1.0
+        latent_image = latent_image.float()
+        if noise is None:
+            noise = prepare_noise(latent_image, seed)
+        sigmas = sigmas_for(ms, scheduler, steps, denoise)
+        fn, disable_cfg1 = _resolve_sampler(sampler_name)
+        extra = {}
+        if sampler_name in _MULTISCALE_WHITELIST:
+            extra = dict(enable_multiscale=enable_multiscale, multiscale_factor=multiscale_factor,
+                         multiscale_fullres_start=multiscale_fullres_start, multiscale_fullres_end=multiscale_fullres_end,
+                         multiscale_intermittent_fullres=multiscale_intermittent_fullres)
+        if torch.count_nonzero(latent_image) > 0:                            # CFG.py:266-269
+            latent_image = (latent_image - FLUX_LATENT_SHIFT) * FLUX_LATENT_SCALE
+        x = ms.noise_scaling(sigmas[0], noise, latent_image).to(self.engine.device)
+        model = FluxCFGDenoiser(self.engine, positive, negative, cfg, guidance, x.shape[0], disable_cfg1_optimization=disable_cfg1)
+        x = fn(model, x, sigmas, trace=trace, **extra)
+        x = ms.inverse_noise_scaling(sigmas[-1], x)
+        return x / FLUX_LATENT_SCALE + FLUX_LATENT_SHIFT                    # process_latent_out
+

@@ -207,8 +207,14 @@ def get_sigmas_karras(n, sigma_min, sigma_max, rho=7.0):
     return torch.cat([sigmas, sigmas.new_zeros([1])])
 
 
-def calculate_sigmas(scheduler_name, steps):
-    """ksampler_util.py:152-271."""
+def calculate_sigmas(scheduler_name, steps, SIGMAS=None):
+    """ksampler_util.py:152-271.  SIGMAS: the model-sampling table (default: SD1.5's 1000 discrete sigmas; Flux passes
+    its 10000-entry shifted table, for which only "simple" and "beta" work in the reference — "normal"/"karras" need
+    sigma_min, which ModelSamplingFlux lacks)."""
+    flux = SIGMAS is not None
+    SIGMAS = globals()["SIGMAS"] if SIGMAS is None else SIGMAS
+    if flux and scheduler_name in ("karras", "normal"):
+        raise AttributeError("'ModelSampling' object has no attribute 'sigma_min'")
     if scheduler_name == "karras":
         return get_sigmas_karras(steps, float(SIGMAS[0]), float(SIGMAS[-1]))
     if scheduler_name == "normal":
@@ -230,12 +236,12 @@ def calculate_sigmas(scheduler_name, steps):
     raise ValueError(scheduler_name)
 
 
-def sigmas_for(scheduler, steps, denoise):
+def sigmas_for(scheduler, steps, denoise, SIGMAS=None):
     """sampling.py:966-985 / KSampler.set_steps :665-676."""
     if denoise is None or denoise > 0.9999:
-        return calculate_sigmas(scheduler, steps)
+        return calculate_sigmas(scheduler, steps, SIGMAS)
     new_steps = int(steps / denoise)
-    return calculate_sigmas(scheduler, new_steps)[-(steps + 1):]
+    return calculate_sigmas(scheduler, new_steps, SIGMAS)[-(steps + 1):]
 
 
 def lcm_pad(conds):
@@ -364,6 +370,44 @@ def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, trace=N
     return x
 
 
+def dy_sampling_step_cfg_pp(x, model_uc, cfg, sigma_next, sigma_hat, current_cfg):
+    """samplers.dy_sampling_step_cfg_pp (samplers.py:362-467): the (1,1) pixel of every 2x2 block forms a half-resolution
+    image c; the model is evaluated on c at sigma_hat (the step's *old* sigma, although x is already at sigma_next); here
+    the hook really sees uncond_denoised, so a second CFG of strength current_cfg is applied on top of the guider's:
+    cfg_denoised = uncond + (denoised - uncond) * current_cfg; Euler update of c to sigma_next; scatter back."""
+    b, ch, hh, ww = x.shape
+    m, n = hh // 2, ww // 2
+    c = x[:, :, 1:2 * m:2, 1:2 * n:2].clone()
+    uncond, cond = model_uc(c, sigma_hat)
+    denoised = torch.lerp(uncond, cond, cfg) if not math.isclose(cfg, 1.0) else cond
+    cfg_denoised = uncond + (denoised - uncond) * current_cfg
+    c = c + ((c - cfg_denoised) / sigma_hat) * (sigma_next - sigma_hat)
+    x = x.clone()
+    x[:, :, 1:2 * m:2, 1:2 * n:2] = c
+    return x
+
+
+def sample_euler_cfgpp(model_uc, x, sigmas, cfg, cfg_scale=7.5, cfg_min=1.0, trace=None):
+    """samplers.sample_euler_dy_cfg_pp (samplers.py:470-609) with its defaults (s_churn 0, s_gamma_* 0 => sigma_hat =
+    sigma_i).  The main step is plain Euler on the guider's output (CFG++ branch dead); after steps
+    i with i // 2 == 1 (and sigma_{i+1} > 0) comes the dy extra step.  model_uc(x, sigma) -> (uncond, cond): the sampler
+    sets disable_cfg1_optimization, so both are always evaluated."""
+    n_steps = len(sigmas) - 1
+    for i in range(n_steps):
+        current_cfg = cfg_scale + (cfg_min - cfg_scale) * (i / n_steps)
+        sigma_hat = sigmas[i]
+        if trace is not None:
+            trace.append(tuple(x.shape[-2:]))
+        uncond, cond = model_uc(x, sigma_hat)
+        denoised = torch.lerp(uncond, cond, cfg) if not math.isclose(cfg, 1.0) else cond
+        x = x + ((x - denoised) / sigma_hat) * (sigmas[i + 1] - sigma_hat)
+        if sigmas[i + 1] > 0 and i // 2 == 1:
+            if trace is not None:
+                trace.append((x.shape[-2] // 2, x.shape[-1] // 2))
+            x = dy_sampling_step_cfg_pp(x, model_uc, cfg, sigmas[i + 1], sigma_hat, current_cfg)
+    return x
+
+
 MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -382,7 +426,9 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
         fn, disable_cfg1 = sample_dpmpp_2m_cfgpp, True
     elif sampler_name == "euler_ancestral_cfgpp":
         fn, disable_cfg1 = sample_euler_ancestral_cfgpp, True
-    elif sampler_name in ("dpmpp_sde_cfgpp", "euler_cfgpp"):
+    elif sampler_name == "euler_cfgpp":
+        fn, disable_cfg1 = sample_euler_cfgpp, True
+    elif sampler_name == "dpmpp_sde_cfgpp":
         raise NotImplementedError(sampler_name)
     else:
         fn, disable_cfg1 = sample_euler, False
@@ -403,7 +449,17 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
     def model(xx, sigma):
         return cfg_denoise(denoiser, xx, sigma, positive, negative, cfg, disable_cfg1)
 
-    x = fn(model, x, sigmas, trace=trace, **extra)
+    if fn is sample_euler_cfgpp:
+        def model_uc(xx, sigma):                                                          # [uncond; cond] batched call
+            bb = xx.shape[0]
+            pos = positive.expand(bb, -1, -1) if positive.shape[0] == 1 else positive
+            neg = negative.expand(bb, -1, -1) if negative.shape[0] == 1 else negative
+            neg, pos = lcm_pad([neg, pos])
+            out = denoiser(torch.cat([xx, xx]), sigma * xx.new_ones([2 * bb]), torch.cat([neg, pos]))
+            return out.chunk(2)
+        x = fn(model_uc, x, sigmas, cfg, trace=trace)
+    else:
+        x = fn(model, x, sigmas, trace=trace, **extra)
     return x / 0.18215                                                                    # CFG.py:294
 
 
@@ -767,3 +823,67 @@ def flux_apply_model(sd, cfg, x, sigma, context, y, guidance):
     """BaseModel.apply_model with CONST (sampling.py:100-155): input unscaled, t = sigma, denoised = x - out*sigma."""
     out = flux_forward(sd, cfg, x, sigma, context, y, guidance)
     return x - out * sigma.view(-1, 1, 1, 1)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Flux sampling path: ModelSamplingFlux + CONST (sampling.py:100-218), Flux1 latent format (Latent.py:114-161)
+def flux_time_shift(mu, sigma, t):
+    """sampling.py:158-169."""
+    return math.exp(mu) / (math.exp(mu) + (1 / t - 1) ** sigma)
+
+
+def flux_model_sigmas(shift=1.15, timesteps=10000):
+    """ModelSamplingFlux.set_parameters (sampling.py:183-195)."""
+    return flux_time_shift(shift, 1.0, torch.arange(1, timesteps + 1, 1) / timesteps)
+
+
+FLUX_SCALE, FLUX_SHIFT = 0.3611, 0.1159
+
+
+def flux_ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positive, negative, latent_image, guidance=3.0,
+                         denoise=1.0, shift=1.15, enable_multiscale=True, multiscale_factor=0.5, multiscale_fullres_start=3,
+                         multiscale_fullres_end=8, multiscale_intermittent_fullres=False, trace=None):
+    """KSampler.sample(flux=True) (sampling.py:773-1233, CFG.py:236-357) for one positive / one negative prompt.
+    positive / negative = (ctx [1,Lt,C], pooled [1,V]); denoiser(x, sigma[B], ctx, y, guidance[B]) is apply_model.
+    CONST: x0 = sigma0*noise + (1-sigma0)*latent, result / (1 - sigma_last); latent format (z - shift)*scale in (non-empty
+    latents only, CFG.py:266-269), z/scale + shift out."""
+    denoise = denoise or 1.0
+    latent_image = latent_image.float()
+    generator = torch.manual_seed(seed)
+    noise = torch.randn(latent_image.size(), dtype=latent_image.dtype, layout=latent_image.layout, generator=generator, device="cpu")
+    table = flux_model_sigmas(shift)
+    sigmas = sigmas_for(scheduler, steps, denoise, table)
+    if torch.count_nonzero(latent_image) > 0:
+        latent_image = (latent_image - FLUX_SHIFT) * FLUX_SCALE
+    x = sigmas[0] * noise + (1.0 - sigmas[0]) * latent_image
+    b = x.shape[0]
+    (pc, py), (nc, ny) = positive, negative
+
+    def model_uc(xx, sigma):
+        bb = xx.shape[0]
+        sig = sigma * xx.new_ones([2 * bb])
+        out = denoiser(torch.cat([xx, xx]), sig, torch.cat([nc.expand(bb, -1, -1), pc.expand(bb, -1, -1)]),
+                       torch.cat([ny.expand(bb, -1), py.expand(bb, -1)]), torch.full([2 * bb], float(guidance)))
+        return out.chunk(2)
+
+    def model(xx, sigma):
+        if math.isclose(cfg, 1.0):
+            bb = xx.shape[0]
+            return denoiser(xx, sigma * xx.new_ones([bb]), pc.expand(bb, -1, -1), py.expand(bb, -1), torch.full([bb], float(guidance)))
+        u, c = model_uc(xx, sigma)
+        return torch.lerp(u, c, cfg)
+
+    if sampler_name == "euler_cfgpp":
+        x = sample_euler_cfgpp(model_uc, x, sigmas, cfg, trace=trace)
+    elif sampler_name in ("dpmpp_2m_cfgpp", "euler_ancestral_cfgpp", "dpmpp_sde_cfgpp"):
+        raise NotImplementedError(sampler_name)
+    else:                                                                                 # unknown names fall back to sample_euler
+        extra = {}
+        if sampler_name in MULTISCALE_WHITELIST:                                          # sampling.py:949-964
+            extra = dict(enable_multiscale=enable_multiscale, multiscale_factor=multiscale_factor,
+                         multiscale_fullres_start=multiscale_fullres_start, multiscale_fullres_end=multiscale_fullres_end,
+                         multiscale_intermittent_fullres=multiscale_intermittent_fullres)
+        x = sample_euler(model, x, sigmas, trace=trace, **extra)
+    x = x / (1.0 - sigmas[-1])                                                            # inverse_noise_scaling
+    return x / FLUX_SCALE + FLUX_SHIFT
+
