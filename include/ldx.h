@@ -161,6 +161,15 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
 
+/* First-block cache (WaveSpeed, src/WaveSpeed/first_block_cache.py:105-384 + fbcache_nodes.py:8-201; the reference's Flux
+ * pipeline enables it with threshold 0.12, pipeline.py:228-231): opt-in APPROXIMATE mode — outputs differ from the exact
+ * forward by design.  After double block 0, r = img_after - img_before; if mean|r_prev - r| / mean|r_prev| < threshold the
+ * remaining blocks are skipped and the cached (final - after-block-0) residual of both streams is added instead; otherwise
+ * they run and both caches refresh.  State resets when the shape changes or sigma[0] does not decrease between calls.
+ * threshold <= 0 disables (default).  Stats count forwards that used / refreshed the cache. */
+int ldx_flux_fbcache(ldx_engine* e, float residual_diff_threshold);
+int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses);
+
 /* ---- T5-XXL text encoder (Flux conditioning) ---------------------------------------------------- */
 /* Keys: T5's state dict ("shared.weight", "encoder.block.0.layer.0.SelfAttention.q.weight", ...,
  * "encoder.block.0.layer.1.DenseReluDense.wi_0.weight", "encoder.final_layer_norm.weight").  The relative-attention

@@ -110,6 +110,22 @@ int ldx_t5_encode(ldx_engine* e, const int32_t* ids, int B, int L, const float* 
     return e->impl->run_t5((const int*)ids, B, L, bias, out, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_flux_fbcache(ldx_engine* e, float residual_diff_threshold) {
+    GUARD_BEGIN
+    if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_fbcache: not a Flux engine"); return LDX_EINVAL; }
+    e->impl->fb_threshold = residual_diff_threshold > 0.f ? residual_diff_threshold : 0.f;
+    e->impl->fb_reset(); e->impl->fb_hits = e->impl->fb_misses = 0;
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses) {
+    GUARD_BEGIN
+    if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_fbcache_stats: not a Flux engine"); return LDX_EINVAL; }
+    if (hits) *hits = e->impl->fb_hits;
+    if (misses) *misses = e->impl->fb_misses;
+    return LDX_OK;
+    GUARD_END
+}
 int ldx_flux_create(const ldx_flux_config* cfg, int device, ldx_engine** out) {
     GUARD_BEGIN
     if (!cfg || !out) { set_error("ldx_flux_create: null argument"); return LDX_EINVAL; }

@@ -725,15 +725,16 @@ int Engine::plan(int B2, int h, int w, int Mc) {
     return LDX_OK;
 }
 
-int Engine::exec_ops(hipStream_t ls) {
+int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
+    if (op_end > ops.size()) op_end = ops.size();
     const bool prof_now = profiling && !prof_graph;
     if (prof_now && prof_events.size() < 2 * ops.size()) {
         const size_t old = prof_events.size();
         prof_events.resize(2 * ops.size());
         for (size_t i = old; i < prof_events.size(); ++i) HIP_OK(hipEventCreate(&prof_events[i]));
     }
-    size_t oi = 0;
-    for (const Op& o : ops) {
+    for (size_t oi = op_begin; oi < op_end; ++oi) {
+        const Op& o = ops[oi];
         if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi], ls));
         switch (o.kind) {
             case OP_PREP: {
@@ -776,11 +777,10 @@ int Engine::exec_ops(hipStream_t ls) {
             case OP_FX_UNPATCH: launch_flux_unpatchify(fx_tok, 4 * o.i1, b_den ? b_x : nullptr, b_s, b_out, o.i0, o.i1, o.i2, o.i3, ls); break;
         }
         if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
-        ++oi;
     }
     if (prof_now) {
         HIP_OK(hipStreamSynchronize(ls));
-        for (size_t i = 0; i < ops.size(); ++i) {
+        for (size_t i = op_begin; i < op_end; ++i) {
             float ms = 0.f;
             HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
             const Op& o = ops[i];

@@ -73,6 +73,13 @@ public:
     int run_t5(const int* ids, int B, int L, const float* bias, float* out, hipStream_t st);
     ldx_flux_config fcfg{};
     int finalize_flux();
+    // First-block cache (WaveSpeed/first_block_cache.py:105-384, fbcache_nodes.py:8-201): opt-in approximate mode
+    float fb_threshold = 0.f; bool fb_have_first = false, fb_have_res = false; float fb_prev_t = 0.f; bool fb_prev_valid = false;
+    size_t fb_a_end = 0, fb_b_end = 0;                 // op ranges: [0, a_end) through double block 0, [a_end, b_end) the rest
+    void *fb_s0 = nullptr, *fb_s1 = nullptr; float *fb_first = nullptr, *fb_res = nullptr, *fb_part = nullptr;
+    void* fb_x = nullptr; int fb_B = 0, fb_L = 0, fb_Lt = 0, fb_C = 0;
+    long fb_hits = 0, fb_misses = 0;
+    void fb_reset() { fb_have_first = fb_have_res = false; fb_prev_valid = false; }
     int plan_flux(int B, int h, int w, int Lt);
     int run_flux(const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,
                  const float* pe_cos, const float* pe_sin, int B, int h, int w, int Lt, bool denoise, float* out, hipStream_t st);
@@ -124,7 +131,7 @@ private:
     bool mk_res(const std::string& pre, int Cin, int Cout, ResW& r);
     bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
 
-    int exec_ops(hipStream_t ls);
+    int exec_ops(hipStream_t ls, size_t op_begin = 0, size_t op_end = (size_t)-1);
     // per-call bindings read by exec_ops
     const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false;
     const int* b_ids = nullptr; float* b_out2 = nullptr;

@@ -132,6 +132,9 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         fx_temb = f32buf((size_t)B * 256); fx_gemb = f32buf((size_t)B * 256); fx_h1 = f32buf((size_t)B * C);
         fx_vec = f32buf((size_t)B * C); fx_svec = f32buf((size_t)B * C); fx_mod = f32buf((size_t)B * fx_mod_total);
         fx_tok = f32buf((size_t)B * Li * inC);
+        // first-block-cache state lives at the head of the arena and is never released: it survives from call to call
+        fb_first = f32buf((size_t)B * Li * C); fb_res = f32buf((size_t)B * L * C); fb_part = f32buf(2 * 1024 + 8);
+        { const size_t o0 = a_alloc((size_t)B * L * C * 2), o1 = a_alloc((size_t)B * L * C * 2); fb_s0 = (void*)((uintptr_t)arena + o0); fb_s1 = (void*)((uintptr_t)arena + o1); }
         auto skinny = [&](const char* name, OpKind kind, const float* x, int ldx_, const LinearW& lw, float* out, int out_act, int accum) {
             Op o{}; o.kind = kind; o.name = name; o.sk = SkinnyArgs{x, ldx_, lw.w, lw.b, out, lw.N, B, lw.N, lw.K, 0, out_act, accum}; ops.push_back(o);
             flops += 2.0 * B * (double)lw.N * lw.K;
@@ -193,7 +196,11 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
 
         // ---- double-stream blocks ----
         Act QKV = new_act(B * L, 3 * C), AO = new_act(B * L, C), N1 = new_act(B * L, C), MLP = new_act(B * L, MH);
+        fb_x = ptr(X); fb_B = B; fb_L = L; fb_Lt = Lt; fb_C = C;
+        int blk_i = 0;
         for (const FluxDoubleW& blk : fx_double) {
+            if (blk_i == 1) fb_a_end = ops.size();
+            ++blk_i;
             for (int b = 0; b < B; ++b) {
                 const float* mb = nullptr; (void)mb;
                 struct S { const FluxStreamW* w; Act x, n, qkv, ao, mlp; int rows; int tok0; };
@@ -215,6 +222,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 }
             }
         }
+        if (blk_i == 1) fb_a_end = ops.size();
         release(MLP);
         // ---- single-stream blocks on the joint sequence ----
         Act CAT = new_act(B * L, C + MH);                      // [attn | gelu(mlp)] : linear2's input (torch.cat, Flux.py:413)
@@ -231,6 +239,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             }
         }
         release(CAT); release(QKV); release(AO);
+        fb_b_end = ops.size();
         // ---- LastLayer on the img rows ----
         for (int b = 0; b < B; ++b) {
             const float* m = fx_mod + (size_t)b * fx_mod_total + fx_final_mod_off;
@@ -243,6 +252,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
     }
     pB2 = B; ph = h; pw = w; pM = Lt;
+    fb_reset();                                        // new shape: the cached residuals no longer apply (fbcache_nodes.py:56-66)
     return LDX_OK;
 }
 
@@ -259,10 +269,52 @@ int Engine::run_flux(const float* x, const float* sigma, const float* ctx, const
     }
     b_x = x; b_s = sigma; b_ctx = ctx; b_y = y; b_guid = guidance; b_cos = pe_cos; b_sin = pe_sin; b_out = out; b_den = denoise;
     prof_graph = false;
-    int rc = exec_ops(st);
-    if (rc) return rc;
+    int rc = LDX_OK;
+    if (fb_threshold <= 0.f) {
+        rc = exec_ops(st);
+    } else {
+        // ---- first-block cache (CachedTransformerBlocks.forward, first_block_cache.py:253-330) ----
+        // ensure_cache_state (fbcache_nodes.py:56-75): reset unless the timestep strictly decreased; the reference reads
+        // timestep[0].item() here, one 4-byte device read per forward
+        float t0 = 0.f;
+        HIP_OK(hipMemcpyAsync(&t0, sigma, sizeof(float), hipMemcpyDeviceToHost, st));
+        HIP_OK(hipStreamSynchronize(st));
+        if (!fb_prev_valid || t0 >= fb_prev_t) fb_reset();
+        const size_t nj = (size_t)fb_B * fb_L * fb_C;
+        // double block 0 with a snapshot of the joint stream in front of it (image rows: original_hidden_states)
+        size_t b0_begin = fb_a_end;
+        for (size_t i = 0; i < fb_a_end; ++i) if (std::string(ops[i].name) == "fx.d.norm1") { b0_begin = i; break; }
+        rc = exec_ops(st, 0, b0_begin);
+        if (rc) return rc;
+        HIP_OK(hipMemcpyAsync(fb_s0, fb_x, nj * 2, hipMemcpyDeviceToDevice, st));
+        rc = exec_ops(st, b0_begin, fb_a_end);
+        if (rc) return rc;
+        bool use = false;
+        if (fb_have_first && fb_have_res) {          // get_can_use_cache -> are_two_tensors_similar (:105-148)
+            launch_fb_diff(fb_x, fb_s0, fb_first, fb_B, fb_L, fb_Lt, fb_C, fb_part, fb_part + 2048, dt, st);
+            float sums[2] = {0.f, 0.f};
+            HIP_OK(hipMemcpyAsync(sums, fb_part + 2048, 2 * sizeof(float), hipMemcpyDeviceToHost, st));
+            HIP_OK(hipStreamSynchronize(st));
+            use = (sums[0] / sums[1]) < fb_threshold;      // mean|prev - cur| / mean|prev| (same element count)
+        }
+        if (use) {
+            launch_fb_apply(fb_x, fb_res, nj, dt, st);                                   // hidden (+ encoder) states += cached residual
+            ++fb_hits;
+        } else {
+            launch_fb_first(fb_x, fb_s0, fb_first, fb_B, fb_L, fb_Lt, fb_C, dt, st);    // set_buffer("first_hidden_states_residual")
+            HIP_OK(hipMemcpyAsync(fb_s1, fb_x, nj * 2, hipMemcpyDeviceToDevice, st));
+            rc = exec_ops(st, fb_a_end, fb_b_end);
+            if (rc) return rc;
+            launch_fb_residual(fb_x, fb_s1, fb_res, nj, dt, st);                         // final - after block 0, both streams
+            fb_have_first = fb_have_res = true;
+            ++fb_misses;
+        }
+        rc = exec_ops(st, fb_b_end, ops.size());
+        fb_prev_t = t0; fb_prev_valid = true;                                            // update_cache_state
+    }
+    if (rc) { fb_reset(); return rc; }
     hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
+    if (e != hipSuccess) { fb_reset(); set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
     return LDX_OK;
 }
 

@@ -127,6 +127,15 @@ void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType
 // CLIP embeddings (clip/Clip.py:254-294): x[b][t][:] = tok[id[b][t]][:] + pos[t][:]  (fp32 tables -> 16-bit)
 void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int T, int C, int vocab, DType dt, hipStream_t s);
 
+// First-block cache helpers on the joint token buffer X [B][L][C] (16-bit; rows [0, Lt) text, [Lt, L) image per batch).
+// fb_diff: sums[0] = sum |(X - S0) - F| , sums[1] = sum |F| over the image rows (deterministic two-stage reduction through
+// `partial`, >= 2 * 1024 floats).  fb_first: F = X - S0 (image rows, fp32).  fb_residual: R = X - S1 (all rows, fp32).
+// fb_apply: X += R.
+void launch_fb_diff(const void* X, const void* S0, const float* F, int B, int L, int Lt, int C, float* partial, float* sums, DType dt, hipStream_t s);
+void launch_fb_first(const void* X, const void* S0, float* F, int B, int L, int Lt, int C, DType dt, hipStream_t s);
+void launch_fb_residual(const void* X, const void* S1, float* R, size_t n, DType dt, hipStream_t s);
+void launch_fb_apply(void* X, const float* R, size_t n, DType dt, hipStream_t s);
+
 // Flux: per-head RMSNorm of q and k (QKNorm, BlackForest/Flux.py:148-200, eps 1e-6) followed by RoPE
 // (apply_rope :73-82) in place on a fused [rows][ld] q|k|v buffer (q at column 0, k at column C = H*D).
 // cos/sin: [L][D/2] fp32 tables built by the host exactly as rope() does (:36-70); token = row % L.

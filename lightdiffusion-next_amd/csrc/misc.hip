@@ -403,4 +403,87 @@ void launch_bilinear(const float* in, float* out, int planes, int Hin, int Win, 
     hipLaunchKernelGGL(bilinear_kernel, dim3(grid_for(total)), dim3(256), 0, s, in, out, planes, Hin, Win, Hout, Wout);
 }
 
+// ------------------------------------------------------------------------------------------
+// First-block cache (WaveSpeed/first_block_cache.py:105-148): elementwise helpers, HBM-bound, 8 values per thread-iteration.
+template <typename T, int MODE>     // MODE 0: diff sums, 1: store first residual
+__global__ __launch_bounds__(256) void fb_img_kernel(const T* X, const T* S0, float* F, int B, int L, int Lt, int C, float* partial) {
+    const int Li = L - Lt, cpr = C / 8;
+    const long total = (long)B * Li * cpr;
+    float sd = 0.f, sp = 0.f;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int ch = (int)(idx % cpr);
+        const long r = idx / cpr;
+        const int b = (int)(r / Li), row = (int)(r % Li);
+        const long xo = ((long)b * L + Lt + row) * C + ch * 8, fo = ((long)b * Li + row) * C + ch * 8;
+        float x[8], s0[8];
+        unpack8<T>(*(const uint4*)(X + xo), x);
+        unpack8<T>(*(const uint4*)(S0 + xo), s0);
+        if (MODE == 0) {
+            const float4 f0 = *(const float4*)(F + fo), f1 = *(const float4*)(F + fo + 4);
+            const float f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sd += fabsf(f[e] - (x[e] - s0[e])); sp += fabsf(f[e]); }
+        } else {
+            *(float4*)(F + fo) = make_float4(x[0] - s0[0], x[1] - s0[1], x[2] - s0[2], x[3] - s0[3]);
+            *(float4*)(F + fo + 4) = make_float4(x[4] - s0[4], x[5] - s0[5], x[6] - s0[6], x[7] - s0[7]);
+        }
+    }
+    if (MODE == 0) {
+        __shared__ float red[2][4];
+        sd = wave_sum(sd); sp = wave_sum(sp);
+        if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = sd; red[1][threadIdx.x >> 6] = sp; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            partial[blockIdx.x] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+            partial[gridDim.x + blockIdx.x] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        }
+    }
+}
+__global__ __launch_bounds__(256) void fb_reduce_kernel(const float* partial, int n, float* sums) {
+    __shared__ float red[2][4];
+    float a = 0.f, b = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) { a += partial[i]; b += partial[n + i]; }      // fixed order per thread
+    a = wave_sum(a); b = wave_sum(b);
+    if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) { sums[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]); sums[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]); }
+}
+void launch_fb_diff(const void* X, const void* S0, const float* F, int B, int L, int Lt, int C, float* partial, float* sums, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * (L - Lt) * (C / 8);
+    int grid = (int)((total + 255) / 256); if (grid > 1024) grid = 1024; if (grid < 1) grid = 1;
+    if (dt == DT_BF16) hipLaunchKernelGGL((fb_img_kernel<__bf16, 0>), dim3(grid), dim3(256), 0, s, (const __bf16*)X, (const __bf16*)S0, (float*)F, B, L, Lt, C, partial);
+    else hipLaunchKernelGGL((fb_img_kernel<_Float16, 0>), dim3(grid), dim3(256), 0, s, (const _Float16*)X, (const _Float16*)S0, (float*)F, B, L, Lt, C, partial);
+    hipLaunchKernelGGL(fb_reduce_kernel, dim3(1), dim3(256), 0, s, partial, grid, sums);
+}
+void launch_fb_first(const void* X, const void* S0, float* F, int B, int L, int Lt, int C, DType dt, hipStream_t s) {
+    const size_t total = (size_t)B * (L - Lt) * (C / 8);
+    if (dt == DT_BF16) hipLaunchKernelGGL((fb_img_kernel<__bf16, 1>), dim3(grid_for(total)), dim3(256), 0, s, (const __bf16*)X, (const __bf16*)S0, F, B, L, Lt, C, nullptr);
+    else hipLaunchKernelGGL((fb_img_kernel<_Float16, 1>), dim3(grid_for(total)), dim3(256), 0, s, (const _Float16*)X, (const _Float16*)S0, F, B, L, Lt, C, nullptr);
+}
+template <typename T, int MODE>     // MODE 0: R = X - S1 ; 1: X += R
+__global__ __launch_bounds__(256) void fb_joint_kernel(T* X, const T* S1, float* R, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        float x[8];
+        unpack8<T>(*(const uint4*)(X + i * 8), x);
+        if (MODE == 0) {
+            float s1[8];
+            unpack8<T>(*(const uint4*)(S1 + i * 8), s1);
+            *(float4*)(R + i * 8) = make_float4(x[0] - s1[0], x[1] - s1[1], x[2] - s1[2], x[3] - s1[3]);
+            *(float4*)(R + i * 8 + 4) = make_float4(x[4] - s1[4], x[5] - s1[5], x[6] - s1[6], x[7] - s1[7]);
+        } else {
+            const float4 r0 = *(const float4*)(R + i * 8), r1 = *(const float4*)(R + i * 8 + 4);
+            x[0] += r0.x; x[1] += r0.y; x[2] += r0.z; x[3] += r0.w; x[4] += r1.x; x[5] += r1.y; x[6] += r1.z; x[7] += r1.w;
+            *(uint4*)(X + i * 8) = pack8<T>(x);
+        }
+    }
+}
+void launch_fb_residual(const void* X, const void* S1, float* R, size_t n, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL((fb_joint_kernel<__bf16, 0>), dim3(grid_for(n / 8)), dim3(256), 0, s, (__bf16*)X, (const __bf16*)S1, R, n / 8);
+    else hipLaunchKernelGGL((fb_joint_kernel<_Float16, 0>), dim3(grid_for(n / 8)), dim3(256), 0, s, (_Float16*)X, (const _Float16*)S1, R, n / 8);
+}
+void launch_fb_apply(void* X, const float* R, size_t n, DType dt, hipStream_t s) {
+    if (dt == DT_BF16) hipLaunchKernelGGL((fb_joint_kernel<__bf16, 1>), dim3(grid_for(n / 8)), dim3(256), 0, s, (__bf16*)X, nullptr, (float*)R, n / 8);
+    else hipLaunchKernelGGL((fb_joint_kernel<_Float16, 1>), dim3(grid_for(n / 8)), dim3(256), 0, s, (_Float16*)X, nullptr, (float*)R, n / 8);
+}
+
 }  // namespace ldx

@@ -433,6 +433,15 @@ class FluxEngine:
                                              lib.current_stream_ptr()), "ldx_flux_forward")
         return out
 
+    def set_fbcache(self, residual_diff_threshold: float):
+        """ApplyFBCacheOnModel.patch (fbcache_nodes.py:8-201): opt-in approximate first-block cache; 0 disables."""
+        lib.check(self._lib.ldx_flux_fbcache(self._h, float(residual_diff_threshold)), "ldx_flux_fbcache")
+
+    def fbcache_stats(self):
+        h, m = C.c_int64(), C.c_int64()
+        lib.check(self._lib.ldx_flux_fbcache_stats(self._h, C.byref(h), C.byref(m)), "ldx_flux_fbcache_stats")
+        return {"hits": h.value, "misses": m.value}
+
     def forward(self, x, timestep, ctx, y, guidance):
         """Flux3.forward(x, timestep, context, y, guidance) (Flux.py:732-778)."""
         return self._run(x, timestep, ctx, y, guidance, False)

@@ -73,6 +73,8 @@ _SIGS = {
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldx_flux_fbcache": (_i, [_vp, _f]),
+    "ldx_flux_fbcache_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldx_t5_create": (_i, [C.POINTER(ldx_t5_config), _i, C.POINTER(_vp)]),
     "ldx_t5_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ldx_flux_create": (_i, [C.POINTER(ldx_flux_config), _i, C.POINTER(_vp)]),

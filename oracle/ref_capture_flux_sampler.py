@@ -102,6 +102,33 @@ def main():
                                        latent_image={"samples": gl}, pipeline=True, disable_pbar=True,
                                        sampler_name="sample_euler", scheduler="simple", flux=True)
     g["flux_i2i_latent"] = gl.numpy(); g["flux_i2i"] = o[0]["samples"].numpy(); g["flux_i2i_calls"] = np.array(calls, dtype=np.float64)
+    # ---- G18: first-block cache (WaveSpeed) on the same sampler runs; threshold chosen so that hits and misses mix
+    from src.WaveSpeed import fbcache_nodes, first_block_cache
+    hits = []
+    orig_similar = first_block_cache.get_can_use_cache
+
+    def spy_can_use(*a, **k):
+        r = orig_similar(*a, **k)
+        hits.append(int(bool(r)))
+        return r
+
+    first_block_cache.get_can_use_cache = spy_can_use
+    for thr, tag in ((0.9, "t90"), (0.12, "t12")):
+        patched = fbcache_nodes.ApplyFBCacheOnModel().patch((fmp,), "diffusion_model", thr)[0]
+        hits.clear()
+        with torch.no_grad():
+            o = sampling.KSampler().sample(model=patched, seed=9, steps=12, cfg=1, denoise=1, positive=fpos, negative=fneg,
+                                           latent_image={"samples": torch.zeros(1, 16, 8, 12)}, pipeline=True, disable_pbar=True,
+                                           sampler_name="euler_cfgpp", scheduler="beta", flux=True)
+        g[f"fb_{tag}_out"] = o[0]["samples"].numpy(); g[f"fb_{tag}_hits"] = np.array(hits)
+        hits.clear()
+        with torch.no_grad():
+            o = sampling.KSampler().sample(model=patched, seed=10, steps=10, cfg=1, denoise=1, positive=fpos, negative=fneg,
+                                           latent_image={"samples": torch.zeros(2, 16, 8, 8)}, pipeline=True, disable_pbar=True,
+                                           sampler_name="sample_euler", scheduler="simple", flux=True)
+        g[f"fb_{tag}_euler_out"] = o[0]["samples"].numpy(); g[f"fb_{tag}_euler_hits"] = np.array(hits)
+        print("fbcache", tag, g[f"fb_{tag}_hits"].tolist(), g[f"fb_{tag}_euler_hits"].tolist())
+    first_block_cache.get_can_use_cache = orig_similar
     np.savez_compressed(os.path.join(OUT, "cfgpp.npz"), **g)
     print("cfgpp.npz", {k: v.shape for k, v in g.items()})
     print("sd calls", g["sd_cfgpp_calls"][:, :2].tolist())

@@ -765,8 +765,36 @@ def _flux_attn(q, k, v, pe):
     return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
 
 
-def flux_forward(sd, cfg, x, timestep, context, y, guidance):
-    """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output."""
+class FluxFBCache:
+    """First-block cache state (WaveSpeed/fbcache_nodes.py:8-201 + first_block_cache.py:105-384) as the reference's Flux
+    pipeline uses it (threshold 0.12, no validation function): reset when the input shape changes or the timestep does not
+    decrease; hit when mean|r_prev - r| / mean|r_prev| < threshold for r = img_after_block0 - img_before."""
+
+    def __init__(self, threshold):
+        self.threshold, self.log = threshold, []
+        self.reset()
+
+    def reset(self):
+        self.first = self.res_img = self.res_txt = None
+        self.prev_t = self.prev_shape = None
+
+    def begin(self, x, t):                                         # ensure_cache_state
+        if self.prev_t is None or self.prev_shape != tuple(x.shape) or t >= self.prev_t:
+            self.reset()
+        self._cur = (tuple(x.shape), t)
+
+    def end(self):                                                 # update_cache_state
+        self.prev_shape, self.prev_t = self._cur
+
+    def can_use(self, r):
+        if self.first is None or self.first.shape != r.shape:
+            return False
+        return float((self.first - r).abs().mean() / self.first.abs().mean()) < self.threshold
+
+
+def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None):
+    """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output.
+    fb: optional FluxFBCache (approximate mode)."""
     w = W(sd)
     lin = lambda name, t: F.linear(t, w(name + ".weight"), w(name + ".bias") if w.has(name + ".bias") else None)
     mlp_emb = lambda name, t: lin(name + ".out_layer", F.silu(lin(name + ".in_layer", t)))
@@ -790,7 +818,12 @@ def flux_forward(sd, cfg, x, timestep, context, y, guidance):
     ln = lambda t: F.layer_norm(t, (C,), eps=1e-6)
     heads = lambda t: t.view(t.shape[0], t.shape[1], 3, H, -1).permute(2, 0, 3, 1, 4)
     lt = txt.shape[1]
+    if fb is not None:
+        fb.begin(x, float(timestep[0]))
+    img_in, skip_rest = img, False
     for i in range(cfg.depth):                                                                 # DoubleStreamBlock.forward :298-348
+        if skip_rest:
+            break
         p = f"double_blocks.{i}."
         im = lin(p + "img_mod.lin", F.silu(vec))[:, None, :].chunk(6, dim=-1)
         tm = lin(p + "txt_mod.lin", F.silu(vec))[:, None, :].chunk(6, dim=-1)
@@ -804,8 +837,18 @@ def flux_forward(sd, cfg, x, timestep, context, y, guidance):
         img = img + im[5] * lin(p + "img_mlp.2", F.gelu(lin(p + "img_mlp.0", (1 + im[4]) * ln(img) + im[3]), approximate="tanh"))
         txt = txt + tm[2] * lin(p + "txt_attn.proj", ta)
         txt = txt + tm[5] * lin(p + "txt_mlp.2", F.gelu(lin(p + "txt_mlp.0", (1 + tm[4]) * ln(txt) + tm[3]), approximate="tanh"))
+        if fb is not None and i == 0:                                                          # CachedTransformerBlocks.forward :253-330
+            r = img - img_in
+            if fb.can_use(r):
+                fb.log.append(1)
+                img, txt, skip_rest = img + fb.res_img, txt + fb.res_txt, True
+            else:
+                fb.log.append(0)
+                fb.first, img_b0, txt_b0 = r, img, txt
     xj = torch.cat((txt, img), 1)
     for i in range(cfg.depth_single_blocks):                                                   # SingleStreamBlock.forward :389-418
+        if skip_rest:
+            break
         p = f"single_blocks.{i}."
         shift, scale, gate = lin(p + "modulation.lin", F.silu(vec))[:, None, :].chunk(3, dim=-1)
         qkv, mlp = torch.split(lin(p + "linear1", (1 + scale) * ln(xj) + shift), [3 * C, cfg.mlp_hidden], dim=-1)
@@ -814,14 +857,18 @@ def flux_forward(sd, cfg, x, timestep, context, y, guidance):
         attn = _flux_attn(q, k, v, pe)
         xj = xj + gate * lin(p + "linear2", torch.cat((attn, F.gelu(mlp, approximate="tanh")), 2))
     img = xj[:, lt:]
+    if fb is not None:
+        if not skip_rest:
+            fb.res_img, fb.res_txt = img - img_b0, xj[:, :lt] - txt_b0
+        fb.end()
     shift, scale = lin("final_layer.adaLN_modulation.1", F.silu(vec)).chunk(2, dim=1)           # LastLayer.forward :455-471
     img = lin("final_layer.linear", (1 + scale[:, None, :]) * ln(img) + shift[:, None, :])
     return img.reshape(bs, hl, wl, c, 2, 2).permute(0, 3, 1, 4, 2, 5).reshape(bs, c, h, wd)
 
 
-def flux_apply_model(sd, cfg, x, sigma, context, y, guidance):
+def flux_apply_model(sd, cfg, x, sigma, context, y, guidance, fb=None):
     """BaseModel.apply_model with CONST (sampling.py:100-155): input unscaled, t = sigma, denoised = x - out*sigma."""
-    out = flux_forward(sd, cfg, x, sigma, context, y, guidance)
+    out = flux_forward(sd, cfg, x, sigma, context, y, guidance, fb=fb)
     return x - out * sigma.view(-1, 1, 1, 1)
 
 

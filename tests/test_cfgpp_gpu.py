@@ -65,3 +65,34 @@ def test_flux_ksampler(ldx, ldx_lib, g, dt, tol):
     r2 = _rel(out, g["flux_i2i"])
     print(f"[{dt}] Flux KSampler: euler_cfgpp/beta rel-L2 {r1:.3e}, img2img euler/simple {r2:.3e}")
     assert r1 <= tol and r2 <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_flux_first_block_cache(ldx, ldx_lib, g, dt, tol):
+    """Opt-in approximate mode (ldx_flux_fbcache): same number of cache hits as the reference's patched model and latents
+    within the sampler tolerance of ITS (approximate) output.  Threshold 0.9 mixes hits and misses on the synthetic weights;
+    0.12 (the pipeline's value) never hits here and must equal the exact path."""
+    cfg = ldx.FluxConfig.tiny()
+    sd = ldx.weights.synth_state_dict(ldx.weights.flux_state_dict_spec(cfg), seed=31, dtype=torch.float32)
+    eng = ldx.FluxEngine(cfg, sd, device=0, dtype=dt)
+    ks = ldx.sampling.FluxKSampler(eng)
+    ctx, y = torch.from_numpy(g["flux_ctx"]), torch.from_numpy(g["flux_y"])
+    neg = (torch.zeros_like(ctx), torch.zeros_like(y))
+    for thr, tag in ((0.9, "t90"), (0.12, "t12")):
+        eng.set_fbcache(thr)
+        out = ks.sample(seed=9, steps=12, cfg=1, sampler_name="euler_cfgpp", scheduler="beta", positive=(ctx, y), negative=neg,
+                        latent_image=torch.zeros(1, 16, 8, 12), guidance=3.0)
+        st = eng.fbcache_stats()
+        ref_hits = int(g[f"fb_{tag}_hits"].sum())
+        r1 = _rel(out, g[f"fb_{tag}_out"])
+        eng.set_fbcache(thr)
+        out = ks.sample(seed=10, steps=10, cfg=1, sampler_name="sample_euler", scheduler="simple", positive=(ctx, y), negative=neg,
+                        latent_image=torch.zeros(2, 16, 8, 8), guidance=3.0)
+        st2 = eng.fbcache_stats()
+        r2 = _rel(out, g[f"fb_{tag}_euler_out"])
+        print(f"[{dt}] FBCache thr {thr}: hits {st['hits']}/{st['hits'] + st['misses']} (ref {ref_hits}), rel-L2 {r1:.3e}; "
+              f"euler hits {st2['hits']} (ref {int(g[f'fb_{tag}_euler_hits'].sum())}), rel-L2 {r2:.3e}")
+        assert st["hits"] == ref_hits and st["hits"] + st["misses"] == len(g[f"fb_{tag}_hits"])
+        assert st2["hits"] == int(g[f"fb_{tag}_euler_hits"].sum())
+        assert r1 <= tol and r2 <= tol
+    eng.set_fbcache(0.0)

@@ -84,3 +84,24 @@ def test_flux_ksampler(g, flux):
                                      negative=(torch.zeros_like(ctx), torch.zeros_like(y)), latent_image=torch.from_numpy(g["flux_i2i_latent"]),
                                      guidance=3.0, denoise=0.6)
     assert _rel(out, g["flux_i2i"]) < 1e-3
+
+
+@pytest.mark.parametrize("thr,tag", [(0.9, "t90"), (0.12, "t12")])
+def test_flux_first_block_cache(g, flux, thr, tag):
+    """WaveSpeed FBCache restatement: identical hit / miss decisions and latents as the reference's patched model."""
+    cfg, sd = flux
+    ctx, y = torch.from_numpy(g["flux_ctx"]), torch.from_numpy(g["flux_y"])
+    neg = (torch.zeros_like(ctx), torch.zeros_like(y))
+    fb = O.FluxFBCache(thr)
+    den = lambda x, s, c, yy, gd: O.flux_apply_model(sd, cfg, x, s, c, yy, gd, fb=fb)      # noqa: E731
+    with torch.no_grad():
+        out = O.flux_ksampler_sample(den, seed=9, steps=12, cfg=1, sampler_name="euler_cfgpp", scheduler="beta", positive=(ctx, y),
+                                     negative=neg, latent_image=torch.zeros(1, 16, 8, 12), guidance=3.0)
+    assert fb.log == [int(v) for v in g[f"fb_{tag}_hits"]]
+    assert _rel(out, g[f"fb_{tag}_out"]) < 1e-3
+    fb.log.clear(); fb.reset()
+    with torch.no_grad():
+        out = O.flux_ksampler_sample(den, seed=10, steps=10, cfg=1, sampler_name="sample_euler", scheduler="simple", positive=(ctx, y),
+                                     negative=neg, latent_image=torch.zeros(2, 16, 8, 8), guidance=3.0)
+    assert fb.log == [int(v) for v in g[f"fb_{tag}_euler_hits"]]
+    assert _rel(out, g[f"fb_{tag}_euler_out"]) < 1e-3
