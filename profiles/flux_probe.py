@@ -40,3 +40,20 @@ print(f"Flux DiT forward 1024^2 bs1 depth {depth}+{single}: {dt*1e3:.1f} ms  {in
 eng.profile(True); eng.denoise(x, t, ctx, y, gd); torch.cuda.synchronize(); eng.profile(False, reset=False)
 for k, v in sorted(eng.profile_report().items(), key=lambda kv: -kv[1]["ms"])[:8]:
     print(f"  {k:30s} n={v['count']:4d} {v['ms']:.2f} ms" + (f"  {v['flops']/v['ms']/1e9:.0f} TF" if v['flops'] else ""))
+
+# ---- the reference's Flux pipeline shape (pipeline.py:237-262): 20 steps euler_cfgpp / beta, cfg 1 with a zeroed negative
+# (both branches evaluated: batch 2), guidance 3.0, optional first-block cache 0.12 ----
+if len(sys.argv) > 3 and sys.argv[3] == "sampler":
+    ks = ldx.sampling.FluxKSampler(eng)
+    pos = (torch.randn(1, 256, 4096), torch.randn(1, 768))
+    neg = (torch.zeros(1, 256, 4096), torch.zeros(1, 768))
+    for thr in (0.0, 0.12):
+        eng.set_fbcache(thr)
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            out = ks.sample(seed=1, steps=20, cfg=1, sampler_name="euler_cfgpp", scheduler="beta", positive=pos, negative=neg,
+                            latent_image=torch.zeros(1, 16, 128, 128), guidance=3.0)
+            torch.cuda.synchronize(); dt = time.perf_counter() - t0
+        st = eng.fbcache_stats()
+        print(f"Flux KSampler 20 steps euler_cfgpp/beta 1024^2 (22 batch-2 forwards), fbcache {thr}: {dt:.2f} s  "
+              f"({20 / dt:.2f} it/s)  cache hits {st['hits']}/{st['hits'] + st['misses']} finite={bool(torch.isfinite(out).all())}")
