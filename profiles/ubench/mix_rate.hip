@@ -9,9 +9,11 @@
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) float f32x4;
 
-// MODE 0: MFMA only, 1: VALU only, 2: both, blocked, 3: both, interleaved 1 MFMA : (NE+NF)/NM VALU
+// MODE 0: MFMA only, 1: VALU only, 2: both, blocked, 3: both, interleaved 1 MFMA : (NE+NF)/NM VALU,
+// 4: blocked, but every second workgroup starts half an iteration late (one extra VALU phase up front), so the two waves
+//    that share a SIMD run in anti-phase
 template <int MODE, int NM, int NE, int NF>
-__global__ __launch_bounds__(256) void k(float* out, int iters, float c) {
+__global__ __launch_bounds__(512) void k(float* out, int iters, float c) {
     f32x4 acc[8];
     bf16x8 a, b;
 #pragma unroll
@@ -21,13 +23,21 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, float c) {
     float e[16];
 #pragma unroll
     for (int i = 0; i < 16; ++i) e[i] = threadIdx.x * 0.001f + i * 0.01f;
+    // anti-phase: with 512-thread workgroups waves w and w+4 share a SIMD; otherwise alternate workgroups
+    if (MODE == 4 && (blockDim.x == 512 ? (threadIdx.x >= 256) : (blockIdx.x & 1))) {
+#pragma unroll
+        for (int v = 0; v < NE; ++v) e[v & 15] = __builtin_amdgcn_exp2f(e[v & 15]);
+#pragma unroll
+        for (int v = 0; v < NF; ++v) e[v & 15] = fmaf(e[v & 15], c, 0.25f);
+        __builtin_amdgcn_sched_barrier(0);
+    }
     for (int it = 0; it < iters; ++it) {
-        if (MODE == 0 || MODE == 2) {
+        if (MODE == 0 || MODE == 2 || MODE == 4) {
 #pragma unroll
             for (int m = 0; m < NM; ++m) acc[m & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, acc[m & 7], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
-        if (MODE == 1 || MODE == 2) {
+        if (MODE == 1 || MODE == 2 || MODE == 4) {
 #pragma unroll
             for (int v = 0; v < NE; ++v) e[v & 15] = __builtin_amdgcn_exp2f(e[v & 15]);
 #pragma unroll
@@ -76,16 +86,37 @@ void run(const char* name) {
     (void)hipFree(d);
 }
 
+template <int MODE, int NM, int NE, int NF>
+void run512(const char* name) {
+    float* d; (void)hipMalloc(&d, 256 * 8 * 1024 * 4);
+    const int iters = 4000;
+    hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    hipLaunchKernelGGL((k<MODE, NM, NE, NF>), dim3(256), dim3(512), 0, 0, d, 10, 1.0001f);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL((k<MODE, NM, NE, NF>), dim3(256), dim3(512), 0, 0, d, iters, 1.0001f);
+    (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+    float ms; (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-34s 512-thread WG, 2 waves/SIMD: %8.1f cycles per wave-iteration (per SIMD @2.4 GHz)\n", name, ms * 1e-3 * 2.4e9 / ((double)iters * 2));
+    (void)hipFree(d);
+}
+
 int main() {
+    run512<2, 56, 68, 210>("blocked 512");
+    run512<4, 56, 68, 210>("blocked 512 anti-phase waves 4-7");
+    run512<2, 56, 68, 100>("blocked 512 56/68/100");
+    run512<4, 56, 68, 100>("blocked 512 anti-phase 56/68/100");
     // the D=40 attention mix per wave and key block (QT=4): 56 MFMA, 68 exp, 210 plain VALU
     run<0, 56, 68, 210>("mfma only        56/0/0");
     run<1, 56, 68, 210>("valu only        0/68/210");
     run<2, 56, 68, 210>("blocked          56/68/210");
     run<3, 56, 68, 210>("interleaved      56/68/210");
+    run<4, 56, 68, 210>("blocked, anti-phase blocks");
     // the pipelined kernel's mix: 56 MFMA, 68 exp, 100 plain VALU
     run<1, 56, 68, 100>("valu only        0/68/100");
     run<2, 56, 68, 100>("blocked          56/68/100");
     run<3, 56, 68, 100>("interleaved      56/68/100");
+    run<4, 56, 68, 100>("blocked anti-phase 56/68/100");
     run<1, 56, 64, 0>("exp only         0/64/0");
     run<3, 56, 64, 0>("interleaved      56/64/0");
     run<3, 56, 0, 112>("interleaved      56/0/112");
