@@ -85,6 +85,17 @@ typedef struct ldx_t5_config {
     int32_t vocab_size;            /* 32128 */
 } ldx_t5_config;
 
+/* ESRGAN RRDBNet (src/UltimateSDUpscale/RDRB.py:216-471): nf 64 / gc 32 dense blocks, 2^num_upscale nearest+conv upsampling. */
+typedef struct ldx_esrgan_config {
+    int32_t compute_dtype;
+    int32_t in_nc;                 /* 3 */
+    int32_t out_nc;                /* 3 */
+    int32_t nf;                    /* 64 */
+    int32_t gc;                    /* 32 */
+    int32_t num_blocks;            /* 23 RRDBs */
+    int32_t num_upscale;           /* 2 -> x4 */
+} ldx_esrgan_config;
+
 /* Flux DiT — FluxParams (src/BlackForest/Flux.py:293-306); flux-dev: 16, 768, 4096, 3072, 4.0, 24, 19, 38,
  * axes [16,56,56], theta 10000, qkv_bias 1, guidance_embed 1. */
 typedef struct ldx_flux_config {
@@ -160,6 +171,18 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
  * (negative counts from the end, e.g. -2 = clip-skip 2; Clip.py:218-236).  Causal mask, no padding mask. */
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
+
+/* ---- ESRGAN upscaler --------------------------------------------------------------------------- */
+/* Keys: RRDBNet's own module names ("model.0.weight", "model.1.sub.0.RDB1.conv1.0.weight", ..., "model.1.sub.<nb>.weight",
+ * "model.3.weight", "model.6.weight", "model.8.weight", "model.10.weight"); newer checkpoint layouts are renamed by the host
+ * exactly as RRDBNet.new_to_old_arch does (RDRB.py:381-441). */
+int ldx_esrgan_create(const ldx_esrgan_config* cfg, int device, ldx_engine** out);
+/* RRDBNet.forward: pixels [B][H][W][in_nc] fp32 -> [B][sH][sW][out_nc] fp32, s = 2^num_upscale (no clamp). */
+int ldx_esrgan_forward(ldx_engine* e, const float* pixels_nhwc, int B, int H, int W, float* out_nhwc, void* stream);
+/* tiled_scale's feathered accumulation (src/Utilities/util.py:557-590): out/div [H][W][C] fp32 += tile [th][tw][C] * mask /
+ * mask at (y0, x0); then ldx_tile_finish: out = out / div (div may be NULL), optionally clamped to [0,1] (USDU_upscaler.py:94). */
+int ldx_tile_blend(const float* tile, int th, int tw, float* out, float* div, int H, int W, int C, int y0, int x0, int feather, void* stream);
+int ldx_tile_finish(float* out, const float* div, int64_t n, int clamp01, void* stream);
 
 /* First-block cache (WaveSpeed, src/WaveSpeed/first_block_cache.py:105-384 + fbcache_nodes.py:8-201; the reference's Flux
  * pipeline enables it with threshold 0.12, pipeline.py:228-231): opt-in APPROXIMATE mode — outputs differ from the exact

@@ -13,8 +13,8 @@ Layout:
   weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
 """
 from . import lib, weights  # noqa: F401
-from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine, FluxEngine, T5Engine, bislerp, latent_upscale  # noqa: F401
+from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine, FluxEngine, T5Engine, ESRGANEngine, bislerp, latent_upscale  # noqa: F401
 VAEEngine = VAEDecoderEngine      # the same engine encodes when encoder.* weights are loaded
-from .weights import VAEConfig, CLIPConfig, FluxConfig, T5Config  # noqa: F401
+from .weights import VAEConfig, CLIPConfig, FluxConfig, T5Config, ESRGANConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
 from . import sampling, parallel  # noqa: F401

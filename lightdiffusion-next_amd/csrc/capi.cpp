@@ -95,6 +95,32 @@ int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_l
     return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_esrgan_create(const ldx_esrgan_config* cfg, int device, ldx_engine** out) {
+    GUARD_BEGIN
+    if (!cfg || !out) { set_error("ldx_esrgan_create: null argument"); return LDX_EINVAL; }
+    int rc = check_device(device);
+    if (rc) return rc;
+    *out = new ldx_engine{new Engine(*cfg, device)};
+    return LDX_OK;
+    GUARD_END
+}
+int ldx_esrgan_forward(ldx_engine* e, const float* pixels_nhwc, int B, int H, int W, float* out_nhwc, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->run_esrgan(pixels_nhwc, B, H, W, out_nhwc, (hipStream_t)stream);
+    GUARD_END
+}
+int ldx_tile_blend(const float* tile, int th, int tw, float* out, float* div, int H, int W, int C, int y0, int x0, int feather, void* stream) {
+    if (!tile || !out || !div || th <= 0 || tw <= 0 || C <= 0 || y0 < 0 || x0 < 0 || y0 + th > H || x0 + tw > W || feather < 0) {
+        set_error("ldx_tile_blend: bad argument (tile must lie inside the output)"); return LDX_EINVAL; }
+    launch_tile_blend(tile, th, tw, out, div, H, W, C, y0, x0, feather, (hipStream_t)stream);
+    return check_launch("ldx_tile_blend");
+}
+int ldx_tile_finish(float* out, const float* div, int64_t n, int clamp01, void* stream) {
+    if (!out || n < 0) { set_error("ldx_tile_finish: bad argument"); return LDX_EINVAL; }
+    launch_tile_finish(out, div, (size_t)n, clamp01, (hipStream_t)stream);
+    return check_launch("ldx_tile_finish");
+}
 int ldx_t5_create(const ldx_t5_config* cfg, int device, ldx_engine** out) {
     GUARD_BEGIN
     if (!cfg || !out) { set_error("ldx_t5_create: null argument"); return LDX_EINVAL; }
@@ -161,6 +187,7 @@ int ldx_finalize(ldx_engine* e) {
     if (e->impl->kind == KIND_CLIP) return e->impl->finalize_clip();
     if (e->impl->kind == KIND_FLUX) return e->impl->finalize_flux();
     if (e->impl->kind == KIND_T5) return e->impl->finalize_t5();
+    if (e->impl->kind == KIND_ESRGAN) return e->impl->finalize_esrgan();
     return e->impl->finalize();
     GUARD_END
 }

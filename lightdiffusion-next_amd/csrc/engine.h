@@ -37,15 +37,15 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
-              OP_PIXPREP, OP_MOMENTS,
+              OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
               OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G };
-enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4 };
+enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp;
     void* cvt_out; size_t cvt_n;
     // generic slots for the small ops: src/dst pointers + dims
-    const void* p0; void* p1; int i0, i1, i2, i3; float f0;
+    const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;
     double flops; double bytes; char klabel[48];
 };
 struct ProfEntry { long count = 0; double ms = 0, flops = 0, bytes = 0; };
@@ -54,6 +54,7 @@ struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
 struct VaeAttnW { NormW norm; LinearW q, k, v, proj; };
 struct ClipLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
+struct RdbW { LinearW c[5]; };
 struct T5LayerW { NormW ln1, ln2; LinearW qkv, o, wi, wo; };
 struct FluxStreamW { LinearW qkv, proj, mlp0, mlp2; float* qs = nullptr; float* ks = nullptr; int mod_off = 0; };
 struct FluxDoubleW { FluxStreamW img, txt; };
@@ -66,6 +67,12 @@ public:
     Engine(const ldx_clip_config& c, int dev);
     Engine(const ldx_flux_config& c, int dev);
     Engine(const ldx_t5_config& c, int dev);
+    Engine(const ldx_esrgan_config& c, int dev);
+    ldx_esrgan_config ecfg{};
+    std::vector<RdbW> es_rdb; LinearW es_first, es_trunk, es_hr, es_last; std::vector<LinearW> es_up;
+    int finalize_esrgan();
+    int plan_esrgan(int B, int H, int W);
+    int run_esrgan(const float* px, int B, int H, int W, float* out, hipStream_t st);
     ldx_t5_config tcfg{};
     std::vector<T5LayerW> t5_layers; NormW t5_final_ln; float* t5_tok = nullptr; const float* b_bias = nullptr;
     int finalize_t5();

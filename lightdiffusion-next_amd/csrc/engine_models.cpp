@@ -254,7 +254,7 @@ int Engine::plan_vae_encode(int B, int Hpx, int Wpx) {
         gn_ws_off = a_alloc((size_t)B * GN_NCHUNK * 32 * 2 * 4);
         int H = Hpx, W = Wpx;
         Act x0 = new_act(B * H * W, 64);
-        { Op o{}; o.kind = OP_PIXPREP; o.name = "vae.enc.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = 3; o.i2 = H * W; o.i3 = 64; ops.push_back(o); }
+        { Op o{}; o.kind = OP_PIXPREP; o.name = "vae.enc.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = 3; o.i2 = H * W; o.i3 = 64; o.f0 = 2.0f; o.f1 = -1.0f; ops.push_back(o); }
         Act hcur = new_act(B * H * W, v.ch);
         op_conv("vae.enc.conv_in", x0, B, H, W, 64, enc_conv_in, 1, H, W, hcur, Act{});
         flops -= 2.0 * B * H * W * (double)v.ch * 9.0 * (64 - 3);

@@ -243,9 +243,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     } else if (p.act == 2) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                    } else if (p.act == 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                     }
                     if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                    if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
                     if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                    if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
+                                  v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
                     if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -255,8 +261,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                         if (rv) x += rv[n + r];
                         if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
                         else if (p.act == 2) x = gelu_tanh_f(x);
+                        else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
                         if (gt) x *= gt[n + r];
+                        if (p.oscale != 0.f) x *= p.oscale;
                         if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+                        if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
                         if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
                         if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
                     }
@@ -311,8 +320,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             if (rv) x += rv[n + r];
             if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
             else if (p.act == 2) x = gelu_tanh_f(x);
+            else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
             if (p.gate) x *= p.gate[(long)(m / p.rows_per_batch) * p.gate_ld + n + r];
+            if (p.oscale != 0.f) x *= p.oscale;
             if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+            if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
             v[r] = x;
         }
         if (full) {
@@ -331,6 +343,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 struct TileSel { int bm, bn; };
 static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     if (geglu) return {128, 128};
+    if (N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
+    if (N <= 64 && splitk <= 1 && (long)((M + 127) / 128) >= 400) return {128, 64};
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     // wave quantisation: 257..511 tiles of 128x128 put two workgroups on some CUs and one on the rest (the launch takes as
     // long as the doubly-loaded CUs); if 128x160 tiles fit one per CU, every CU runs a single, 1.25x larger tile instead
@@ -358,7 +372,9 @@ static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
 template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
-    if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);
+    if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
+    else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);
+    else if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);
     else if (t.bn == 160) launch_gemm_inst<T, MODE, 128, 160>(a, S, s);
     else launch_gemm_inst<T, MODE, 128, 128>(a, S, s);
 }

@@ -35,9 +35,11 @@ struct GemmArgs {
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
     int geglu;                     // 1: N is 2*inner with slab-interleaved (a|g) rows, out width N/2: a * gelu_erf(g); 2: a * gelu_tanh(g)
     int act;                       // 0 none, 1 quick-GELU x*sigmoid(1.702x) after bias (CLIP MLP, clip/Clip.py:74-77),
-                                   // 2 tanh-GELU (Flux MLPs, BlackForest/Flux.py:279,388)
+                                   // 2 tanh-GELU (Flux MLPs, BlackForest/Flux.py:279,388), 3 LeakyReLU(0.2) (ESRGAN, USDU_util.py:7-10)
     const float* gate; int gate_ld; // per-batch channel gate (Flux adaLN): v *= gate[(m / rows_per_batch)][n] before + R
     const void* R; int ldr;        // residual (16-bit) or null
+    float oscale;                  // != 0: v *= oscale before + R   (ResidualDenseBlock_5C: x5 * 0.2 + x, RDRB.py:205)
+    const void* R2; int ldr2; float oscale2;   // R2 != null: v = v * oscale2 + R2 after + R  (RRDB: out * 0.2 + x, RDRB.py:76)
     void* C; int ldc;              // 16-bit output or null
     float* Cf; int ldcf;           // fp32 output or null
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
@@ -119,7 +121,7 @@ void launch_nchw_to_nhwc(const float* in, void* out, int B, int C, int HW, int C
 // (post_quant_conv, fp32: out[c] = b[c] + sum_k w[c][k] z[k]) -> NHWC 16-bit with Cpad channels.
 void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, const float* mix_w, const float* mix_b, DType dt, hipStream_t s);
 // encoder input: pixels NHWC fp32 [B][HW][C] in [0,1] -> x*2-1 (process_input, VariationalAE.py:593) -> NHWC 16-bit, Cpad channels
-void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, DType dt, hipStream_t s);
+void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, float scale, float shift, DType dt, hipStream_t s);
 // pixel post-process: out = clamp((x + 1) / 2, 0, 1) on fp32 (process_output, VariationalAE.py:595-597)
 void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s);
 // row softmax in place on a 16-bit [rows][ld] matrix: p = softmax(x * scale) (VAE AttnBlock, D = 512 single head)
@@ -135,6 +137,12 @@ void launch_fb_diff(const void* X, const void* S0, const float* F, int B, int L,
 void launch_fb_first(const void* X, const void* S0, float* F, int B, int L, int Lt, int C, DType dt, hipStream_t s);
 void launch_fb_residual(const void* X, const void* S1, float* R, size_t n, DType dt, hipStream_t s);
 void launch_fb_apply(void* X, const float* R, size_t n, DType dt, hipStream_t s);
+
+// tiled_scale blending (Utilities/util.py:406-600): out[y0+y][x0+x][c] += tile[y][x][c] * mask(y, x), div += mask, where mask
+// ramps (t + 1) / feather over the first / last `feather` rows and columns of the tile (all four edges, skipped per axis if
+// feather >= tile extent); finish: out = clamp(out / div, 0, 1) (USDU_upscaler.py:94).  NHWC fp32, C channels.
+void launch_tile_blend(const float* tile, int th, int tw, float* out, float* div, int H, int W, int C, int y0, int x0, int feather, hipStream_t s);
+void launch_tile_finish(float* out, const float* div, size_t n, int clamp01, hipStream_t s);
 
 // Flux: per-head RMSNorm of q and k (QKNorm, BlackForest/Flux.py:148-200, eps 1e-6) followed by RoPE
 // (apply_rope :73-82) in place on a fused [rows][ld] q|k|v buffer (q at column 0, k at column C = H*D).

@@ -164,7 +164,7 @@ void launch_vae_prep(const float* z, void* out, int B, int C, int HW, int Cpad, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void pixels_prep_kernel(const float* px, T* out, int B, int C, int HW, int Cpad) {
+__global__ __launch_bounds__(256) void pixels_prep_kernel(const float* px, T* out, int B, int C, int HW, int Cpad, float scale, float shift) {
     const int cpp = Cpad / 8;
     const long total = (long)B * HW * cpp;
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
@@ -172,14 +172,14 @@ __global__ __launch_bounds__(256) void pixels_prep_kernel(const float* px, T* ou
         const long bp = idx / cpp;
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { const int c = ch * 8 + e; f[e] = c < C ? px[bp * C + c] * 2.0f - 1.0f : 0.f; }
+        for (int e = 0; e < 8; ++e) { const int c = ch * 8 + e; f[e] = c < C ? px[bp * C + c] * scale + shift : 0.f; }
         *(uint4*)(out + bp * Cpad + ch * 8) = pack8<T>(f);
     }
 }
-void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, DType dt, hipStream_t s) {
+void launch_pixels_prep(const float* px, void* out, int B, int C, int HW, int Cpad, float scale, float shift, DType dt, hipStream_t s) {
     const size_t total = (size_t)B * HW * (Cpad / 8);
-    if (dt == DT_BF16) hipLaunchKernelGGL((pixels_prep_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, px, (__bf16*)out, B, C, HW, Cpad);
-    else hipLaunchKernelGGL((pixels_prep_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, px, (_Float16*)out, B, C, HW, Cpad);
+    if (dt == DT_BF16) hipLaunchKernelGGL((pixels_prep_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, px, (__bf16*)out, B, C, HW, Cpad, scale, shift);
+    else hipLaunchKernelGGL((pixels_prep_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, px, (_Float16*)out, B, C, HW, Cpad, scale, shift);
 }
 
 __global__ __launch_bounds__(256) void clamp01_kernel(const float* in, float* out, size_t n) {
@@ -484,6 +484,39 @@ void launch_fb_residual(const void* X, const void* S1, float* R, size_t n, DType
 void launch_fb_apply(void* X, const float* R, size_t n, DType dt, hipStream_t s) {
     if (dt == DT_BF16) hipLaunchKernelGGL((fb_joint_kernel<__bf16, 1>), dim3(grid_for(n / 8)), dim3(256), 0, s, (__bf16*)X, nullptr, (float*)R, n / 8);
     else hipLaunchKernelGGL((fb_joint_kernel<_Float16, 1>), dim3(grid_for(n / 8)), dim3(256), 0, s, (_Float16*)X, nullptr, (float*)R, n / 8);
+}
+
+// ------------------------------------------------------------------------------------------
+// tiled_scale blending (Utilities/util.py:557-590)
+__global__ __launch_bounds__(256) void tile_blend_kernel(const float* tile, int th, int tw, float* out, float* div, int H, int W, int C,
+                                                         int y0, int x0, int feather) {
+    const long total = (long)th * tw * C;
+    const bool fy = feather < th, fx = feather < tw;                  // "if feather >= mask.shape[d]: continue"
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+        const int c = (int)(idx % C);
+        const long px = idx / C;
+        const int x = (int)(px % tw), y = (int)(px / tw);
+        float m = 1.0f;
+        // mask.narrow(d, t, 1).mul_(a) and .narrow(d, size-1-t, 1).mul_(a), a = (t+1)/feather: both may hit the same line
+        if (fy) { if (y < feather) m *= (float)(y + 1) / (float)feather; if (th - 1 - y < feather) m *= (float)(th - y) / (float)feather; }
+        if (fx) { if (x < feather) m *= (float)(x + 1) / (float)feather; if (tw - 1 - x < feather) m *= (float)(tw - x) / (float)feather; }
+        const long o = ((long)(y0 + y) * W + (x0 + x)) * C + c;
+        out[o] += tile[idx] * m;
+        div[o] += m;
+    }
+}
+void launch_tile_blend(const float* tile, int th, int tw, float* out, float* div, int H, int W, int C, int y0, int x0, int feather, hipStream_t s) {
+    hipLaunchKernelGGL(tile_blend_kernel, dim3(grid_for((size_t)th * tw * C)), dim3(256), 0, s, tile, th, tw, out, div, H, W, C, y0, x0, feather);
+}
+__global__ __launch_bounds__(256) void tile_finish_kernel(float* out, const float* div, size_t n, int clamp01) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        float v = div ? out[i] / div[i] : out[i];
+        if (clamp01) v = fminf(fmaxf(v, 0.f), 1.f);
+        out[i] = v;
+    }
+}
+void launch_tile_finish(float* out, const float* div, size_t n, int clamp01, hipStream_t s) {
+    hipLaunchKernelGGL(tile_finish_kernel, dim3(grid_for(n)), dim3(256), 0, s, out, div, n, clamp01);
 }
 
 }  // namespace ldx

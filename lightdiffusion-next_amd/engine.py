@@ -289,6 +289,70 @@ class CLIPTextEngine:
     __del__ = UNetEngine.__del__
 
 
+class ESRGANEngine:
+    """RRDBNet.forward (src/UltimateSDUpscale/RDRB.py:216-471) + tiled_scale (src/Utilities/util.py:406-640) as
+    UpscaleModelLoader / ImageUpscaleWithModel use them (USDU_upscaler.py:48-96)."""
+
+    def __init__(self, cfg, state_dict, device: int = 0, dtype: str = "bf16"):
+        import math as _m
+        from .weights import esrgan_new_to_old_arch
+        self._lib = lib.load()
+        self._h = C.c_void_p()
+        self.cfg, self.device = cfg, torch.device("cuda", device)
+        c = lib.ldx_esrgan_config()
+        c.compute_dtype = {"bf16": lib.LDX_BF16, "f16": lib.LDX_F16, "fp16": lib.LDX_F16}[dtype]
+        c.in_nc, c.out_nc, c.nf, c.gc, c.num_blocks, c.num_upscale = cfg.in_nc, cfg.out_nc, cfg.nf, cfg.gc, cfg.num_blocks, int(_m.log2(cfg.scale))
+        lib.check(self._lib.ldx_esrgan_create(C.byref(c), device, C.byref(self._h)), "ldx_esrgan_create")
+        _load_state_dict(self._lib, self._h, esrgan_new_to_old_arch(state_dict))
+        lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+
+    def forward(self, pixels):
+        """pixels [B,H,W,in_nc] fp32 (device) -> [B, s*H, s*W, out_nc] fp32."""
+        assert pixels.is_cuda and pixels.dtype == torch.float32 and pixels.dim() == 4
+        b, h, w, _ = pixels.shape
+        s = self.cfg.scale
+        out = torch.empty((b, s * h, s * w, self.cfg.out_nc), device=pixels.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_esrgan_forward(self._h, lib.ptr(pixels.contiguous()), b, h, w, lib.ptr(out), lib.current_stream_ptr()),
+                  "ldx_esrgan_forward")
+        return out
+
+    def upscale(self, image, tile: int = 512, overlap: int = 32):
+        """ImageUpscaleWithModel.upscale (USDU_upscaler.py:48-96): tiled_scale(tile 512, overlap 32) then clamp to [0, 1].
+        image [B,H,W,3] fp32 in [0,1] (any device) -> [B, sH, sW, 3] on the engine's device.  Tile positions, the
+        single-tile shortcut and the feather mask follow tiled_scale_multidim (util.py:406-600) exactly."""
+        L, s = self._lib, self.cfg.scale
+        image = image.to(self.device, torch.float32).contiguous()
+        b, h, w, c = image.shape
+        outs = []
+        for bi in range(b):
+            img = image[bi:bi + 1]
+            if h <= tile and w <= tile:
+                out = self.forward(img)
+                lib.check(L.ldx_tile_finish(lib.ptr(out), None, out.numel(), 1, lib.current_stream_ptr()), "ldx_tile_finish")
+                outs.append(out)
+                continue
+            out = torch.zeros((1, s * h, s * w, self.cfg.out_nc), device=self.device, dtype=torch.float32)
+            div = torch.zeros_like(out)
+            ys = range(0, h - overlap, tile - overlap) if h > tile else [0]
+            xs = range(0, w - overlap, tile - overlap) if w > tile else [0]
+            for y in ys:
+                for x in xs:
+                    py, px = max(0, min(h - overlap, y)), max(0, min(w - overlap, x))
+                    ly, lx = min(tile, h - py), min(tile, w - px)
+                    ps = self.forward(img[:, py:py + ly, px:px + lx, :].contiguous())
+                    lib.check(L.ldx_tile_blend(lib.ptr(ps), s * ly, s * lx, lib.ptr(out), lib.ptr(div), s * h, s * w, self.cfg.out_nc,
+                                               round(s * py), round(s * px), round(s * overlap), lib.current_stream_ptr()), "ldx_tile_blend")
+            lib.check(L.ldx_tile_finish(lib.ptr(out), lib.ptr(div), out.numel(), 1, lib.current_stream_ptr()), "ldx_tile_finish")
+            outs.append(out)
+        return torch.cat(outs, 0)
+
+    profile = UNetEngine.profile
+    profile_report = UNetEngine.profile_report
+    plan_info = UNetEngine.plan_info
+    close = UNetEngine.close
+    __del__ = UNetEngine.__del__
+
+
 def t5_relative_position_bucket(relative_position, num_buckets=32, max_distance=128):
     """T5Attention._relative_position_bucket, bidirectional (src/clip/FluxClip.py:152-205) — same torch ops in the same
     order, so bucket boundaries (float32 log) agree bit for bit with the reference."""

@@ -43,6 +43,11 @@ class ldx_clip_config(C.Structure):
                 ("intermediate_size", C.c_int32), ("max_positions", C.c_int32), ("vocab_size", C.c_int32)]
 
 
+class ldx_esrgan_config(C.Structure):
+    _fields_ = [("compute_dtype", C.c_int32), ("in_nc", C.c_int32), ("out_nc", C.c_int32), ("nf", C.c_int32), ("gc", C.c_int32),
+                ("num_blocks", C.c_int32), ("num_upscale", C.c_int32)]
+
+
 class ldx_t5_config(C.Structure):
     _fields_ = [("compute_dtype", C.c_int32), ("d_model", C.c_int32), ("d_ff", C.c_int32), ("num_layers", C.c_int32),
                 ("num_heads", C.c_int32), ("vocab_size", C.c_int32)]
@@ -75,6 +80,10 @@ _SIGS = {
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
     "ldx_flux_fbcache": (_i, [_vp, _f]),
     "ldx_flux_fbcache_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
+    "ldx_esrgan_create": (_i, [C.POINTER(ldx_esrgan_config), _i, C.POINTER(_vp)]),
+    "ldx_esrgan_forward": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
+    "ldx_tile_blend": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp]),
+    "ldx_tile_finish": (_i, [_vp, _vp, _i64, _i, _vp]),
     "ldx_t5_create": (_i, [C.POINTER(ldx_t5_config), _i, C.POINTER(_vp)]),
     "ldx_t5_encode": (_i, [_vp, _vp, _i, _i, _vp, _vp, _vp]),
     "ldx_flux_create": (_i, [C.POINTER(ldx_flux_config), _i, C.POINTER(_vp)]),

@@ -310,6 +310,72 @@ def clip_state_dict_spec(cfg: CLIPConfig):
 
 # ------------------------------------------------------------------------------------------------------
 @dataclass
+class ESRGANConfig:
+    """RRDBNet as the reference builds it (src/UltimateSDUpscale/RDRB.py:216-378): nf 64, gc 32, `num_blocks` RRDBs,
+    log2(scale) upconv stages; defaults = RealESRGAN_x4plus / ESRGAN x4."""
+
+    in_nc: int = 3
+    out_nc: int = 3
+    nf: int = 64
+    gc: int = 32
+    num_blocks: int = 23
+    scale: int = 4
+
+    @staticmethod
+    def tiny() -> "ESRGANConfig":
+        return ESRGANConfig(num_blocks=2)
+
+
+def esrgan_state_dict_spec(cfg: ESRGANConfig):
+    """RRDBNet's own ("old arch") module keys in creation order (RDRB.py:300-378)."""
+    nf, gc, nu = cfg.nf, cfg.gc, int(math.log2(cfg.scale))
+    spec = [("model.0.weight", (nf, cfg.in_nc, 3, 3)), ("model.0.bias", (nf,))]
+    for i in range(cfg.num_blocks):
+        for k in (1, 2, 3):
+            for j in range(5):
+                p = f"model.1.sub.{i}.RDB{k}.conv{j + 1}.0"
+                co = gc if j < 4 else nf
+                spec += [(p + ".weight", (co, nf + j * gc, 3, 3)), (p + ".bias", (co,))]
+    spec += [(f"model.1.sub.{cfg.num_blocks}.weight", (nf, nf, 3, 3)), (f"model.1.sub.{cfg.num_blocks}.bias", (nf,))]
+    for u in range(nu):
+        spec += [(f"model.{3 * (u + 1)}.weight", (nf, nf, 3, 3)), (f"model.{3 * (u + 1)}.bias", (nf,))]
+    spec += [(f"model.{3 * nu + 2}.weight", (nf, nf, 3, 3)), (f"model.{3 * nu + 2}.bias", (nf,)),
+             (f"model.{3 * nu + 4}.weight", (cfg.out_nc, nf, 3, 3)), (f"model.{3 * nu + 4}.bias", (cfg.out_nc,))]
+    return spec
+
+
+def esrgan_new_to_old_arch(state):
+    """RRDBNet.new_to_old_arch (RDRB.py:381-441): Real-ESRGAN / BSRGAN key names -> the module's own names.  A state dict
+    already in the old layout is returned unchanged."""
+    import re
+    if any(k.startswith("model.") for k in state):
+        return dict(state)
+    out = {}
+    nb = 1 + max(int(m.group(1)) for k in state for m in [re.match(r"(?:RRDB_trunk|body)\.(\d+)\.", k)] if m)
+    ren = {"conv_first": "model.0", "trunk_conv": f"model.1.sub.{nb}", "conv_body": f"model.1.sub.{nb}"}
+    max_up = 0
+    for k, v in state.items():
+        base, kind = k.rsplit(".", 1)
+        m = re.match(r"(?:RRDB_trunk|body)\.(\d+)\.(?:RDB|rdb)(\d)\.conv(\d+)$", base)
+        u = re.match(r"(?:upconv|conv_up)(\d)$", base)
+        if base in ren:
+            out[f"{ren[base]}.{kind}"] = v
+        elif m:
+            out[f"model.1.sub.{m.group(1)}.RDB{m.group(2)}.conv{m.group(3)}.0.{kind}"] = v
+        elif u:
+            out[f"model.{int(u.group(1)) * 3}.{kind}"] = v
+            max_up = max(max_up, int(u.group(1)) * 3)
+    for k, v in state.items():
+        base, kind = k.rsplit(".", 1)
+        if base in ("HRconv", "conv_hr"):
+            out[f"model.{max_up + 2}.{kind}"] = v
+        elif base == "conv_last":
+            out[f"model.{max_up + 4}.{kind}"] = v
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+@dataclass
 class T5Config:
     """src/clip/clip/t5_config_xxl.json as read by T5 (src/clip/FluxClip.py:476-519); defaults = T5-XXL encoder."""
 

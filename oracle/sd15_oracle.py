@@ -934,3 +934,69 @@ def flux_ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, po
     x = x / (1.0 - sigmas[-1])                                                            # inverse_noise_scaling
     return x / FLUX_SCALE + FLUX_SHIFT
 
+
+# ---------------------------------------------------------------------------------------------------
+# ESRGAN RRDBNet + tiled_scale (src/UltimateSDUpscale/RDRB.py:10-471, USDU_util.py:36-138, Utilities/util.py:406-640)
+def rrdbnet_forward(sd, cfg, x):
+    """RRDBNet.forward on NCHW fp32; keys = the module's own names (model.0, model.1.sub.i.RDBk.convj.0, ...)."""
+    w = W(sd)
+    conv = lambda name, t: F.conv2d(t, w(name + ".weight"), w(name + ".bias"), padding=1)      # noqa: E731
+    lrelu = lambda t: F.leaky_relu(t, 0.2)                                                        # noqa: E731
+    fea = conv("model.0", x.float())
+    h = fea
+    for i in range(cfg.num_blocks):
+        rin = h
+        for k in (1, 2, 3):                                                                       # ResidualDenseBlock_5C.forward :199-205
+            p = f"model.1.sub.{i}.RDB{k}.conv"
+            x1 = lrelu(conv(p + "1.0", h))
+            x2 = lrelu(conv(p + "2.0", torch.cat((h, x1), 1)))
+            x3 = lrelu(conv(p + "3.0", torch.cat((h, x1, x2), 1)))
+            x4 = lrelu(conv(p + "4.0", torch.cat((h, x1, x2, x3), 1)))
+            x5 = conv(p + "5.0", torch.cat((h, x1, x2, x3, x4), 1))
+            h = x5 * 0.2 + h
+        h = h * 0.2 + rin                                                                         # RRDB.forward :72-76
+    h = fea + conv(f"model.1.sub.{cfg.num_blocks}", h)                                            # ShortcutBlock
+    nu = int(math.log2(cfg.scale))
+    for u in range(nu):
+        h = lrelu(conv(f"model.{3 * (u + 1)}", F.interpolate(h, scale_factor=2, mode="nearest")))
+    h = lrelu(conv(f"model.{3 * nu + 2}", h))
+    return conv(f"model.{3 * nu + 4}", h)
+
+
+def tiled_scale(samples, function, tile_x=64, tile_y=64, overlap=8, upscale_amount=4, out_channels=3):
+    """tiled_scale -> tiled_scale_multidim (util.py:406-640) for 2-D tiles, NCHW."""
+    tile = (tile_y, tile_x)
+    output = torch.empty([samples.shape[0], out_channels, round(samples.shape[2] * upscale_amount), round(samples.shape[3] * upscale_amount)])
+    for b in range(samples.shape[0]):
+        s = samples[b:b + 1]
+        if all(s.shape[d + 2] <= tile[d] for d in range(2)):
+            output[b:b + 1] = function(s)
+            continue
+        out = torch.zeros([1, out_channels] + list(output.shape[2:]))
+        out_div = torch.zeros_like(out)
+        positions = [range(0, s.shape[d + 2] - overlap, tile[d] - overlap) if s.shape[d + 2] > tile[d] else [0] for d in range(2)]
+        for y in positions[0]:
+            for x in positions[1]:
+                s_in, up = s, []
+                for d, it in ((0, y), (1, x)):
+                    pos = max(0, min(s.shape[d + 2] - overlap, it))
+                    ln = min(tile[d], s.shape[d + 2] - pos)
+                    s_in = s_in.narrow(d + 2, pos, ln)
+                    up.append(round(pos * upscale_amount))
+                ps = function(s_in)
+                mask = torch.ones_like(ps)
+                feather = round(overlap * upscale_amount)
+                for d in (2, 3):
+                    if feather >= mask.shape[d]:
+                        continue
+                    for t in range(feather):
+                        a = (t + 1) / feather
+                        mask.narrow(d, t, 1).mul_(a)
+                        mask.narrow(d, mask.shape[d] - 1 - t, 1).mul_(a)
+                o = out.narrow(2, up[0], mask.shape[2]).narrow(3, up[1], mask.shape[3])
+                od = out_div.narrow(2, up[0], mask.shape[2]).narrow(3, up[1], mask.shape[3])
+                o.add_(ps * mask)
+                od.add_(mask)
+        output[b:b + 1] = out / out_div
+    return output
+
