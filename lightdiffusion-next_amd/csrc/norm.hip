@@ -12,6 +12,7 @@
 // order (deterministic, no atomics) and written as per-(batch, pixel-chunk, group) partials.
 // The apply kernel folds the partials into mean/rstd, pre-multiplies gamma/beta into one FMA per
 // element and fuses SiLU.  Statistics are fp32 over the exact 16-bit inputs.
+#include <stdlib.h>
 #include "ldx_device.h"
 #include "ldx_kernels.h"
 
@@ -213,12 +214,20 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
         const int ch = sub + LPR * i;
         if (ch < nch && live) {
             float o[8];
+            // affine / modulation vectors as 16-byte loads (scalar per-element loads made this kernel VMEM-issue bound: 3x slower)
+            auto ld8 = [&](const float* v, float (&d)[8]) {
+                const float4 a = *(const float4*)(v + ch * 8), b = *(const float4*)(v + ch * 8 + 4);
+                d[0] = a.x; d[1] = a.y; d[2] = a.z; d[3] = a.w; d[4] = b.x; d[5] = b.y; d[6] = b.z; d[7] = b.w;
+            };
+            float gg[8], bb[8], sc[8], sh[8];
+            if (p.gamma) ld8(p.gamma, gg);
+            if (p.gamma && p.beta) ld8(p.beta, bb);
+            if (p.scale) { ld8(p.scale + mb, sc); ld8(p.shift + mb, sh); }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const int c = ch * 8 + e;
                 float v = (f[i][e] - mean) * rstd;
-                if (p.gamma) v = v * p.gamma[c] + (p.beta ? p.beta[c] : 0.f);
-                if (p.scale) v = (1.0f + p.scale[mb + c]) * v + p.shift[mb + c];
+                if (p.gamma) v = v * gg[e] + (p.beta ? bb[e] : 0.f);
+                if (p.scale) v = (1.0f + sc[e]) * v + sh[e];
                 o[e] = v;
             }
             *(uint4*)(y + ch * 8) = pack8<T>(o);
@@ -232,6 +241,9 @@ static void launch_ln_t(const LayerNormArgs& a, hipStream_t s) {
     dim3 block(256);
 #define LDX_LN(LPR, NCH) do { const int rpb = 4 * (64 / LPR); \
         hipLaunchKernelGGL((ln_kernel<T, LPR, NCH>), dim3((unsigned)((a.rows + rpb - 1) / rpb)), block, 0, s, a); } while (0)
+    static const int force = getenv("LDX_LN_LPR") ? atoi(getenv("LDX_LN_LPR")) : 0;
+    if (force == 64 && nch <= 192) { LDX_LN(64, 3); return; }
+    if (force == 32 && nch <= 96) { LDX_LN(32, 3); return; }
     if (nch <= 48) LDX_LN(16, 3);              // C <= 384  (SD1.5 level 0: 320)
     else if (nch <= 96) LDX_LN(32, 3);         // C <= 768  (640, CLIP 768)
     else if (nch <= 192) LDX_LN(64, 3);        // C <= 1536 (1280)
