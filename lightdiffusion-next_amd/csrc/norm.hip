@@ -259,37 +259,46 @@ void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s) {
 }
 
 // ------------------------------------------------------------------------------------------
-// Flux q/k: per-head RMSNorm + rotary embedding, in place.  One thread per (row, q|k, head, pair).
+// Flux q/k: per-head RMSNorm + rotary embedding, in place.  One thread per 8 consecutive elements (4 rotary pairs, one
+// 16-byte load / store); the D/8 threads of a head reduce the sum of squares with xor shuffles.
 template <typename T>
 __global__ __launch_bounds__(256) void qk_norm_rope_kernel(const QkRopeArgs p) {
-    const int hp = p.D >> 1;                                   // pairs per head (power of two <= 64)
-    const long total = (long)p.rows * 2 * p.H * hp;
+    const int cpt = p.D >> 3;                                  // threads (16-B chunks) per head: 2..16, power of two
+    const long total = (long)p.rows * 2 * p.H * cpt;
     const long idx = (long)blockIdx.x * 256 + threadIdx.x;
     const bool live = idx < total;
     const long i = live ? idx : total - 1;
-    const int pr = (int)(i % hp);
-    long r = i / hp;
+    const int ch = (int)(i % cpt);
+    long r = i / cpt;
     const int h = (int)(r % p.H); r /= p.H;
     const int which = (int)(r & 1);                            // 0 = q, 1 = k
     const long row = r >> 1;
-    T* __restrict__ ptr = (T*)p.QKV + row * p.ld + which * (p.H * p.D) + h * p.D + pr * 2;
-    const unsigned int raw = *(const unsigned int*)ptr;
-    union { unsigned int u; T t[2]; } in; in.u = raw;
-    const float x0 = (float)in.t[0], x1 = (float)in.t[1];
-    float ss = x0 * x0 + x1 * x1;
-    for (int o = hp >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+    T* __restrict__ ptr = (T*)p.QKV + row * p.ld + which * (p.H * p.D) + h * p.D + ch * 8;
+    float x[8];
+    unpack8<T>(*(const uint4*)ptr, x);
+    float ss = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) ss = fmaf(x[e], x[e], ss);
+    for (int o = cpt >> 1; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
     const float rr = rsqrtf(ss / (float)p.D + p.eps);
-    const float* sc = which ? p.kscale : p.qscale;
-    const float a = x0 * rr * sc[pr * 2], b = x1 * rr * sc[pr * 2 + 1];
+    const float* sc = (which ? p.kscale : p.qscale) + ch * 8;
+    const float4 s0 = *(const float4*)sc, s1 = *(const float4*)(sc + 4);
+    const float sv[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
     const int tok = (int)(row % p.L);
-    const float cs = p.cosT[(long)tok * hp + pr], sn = p.sinT[(long)tok * hp + pr];
-    union { unsigned int u; T t[2]; } out;
-    out.t[0] = (T)(cs * a - sn * b);
-    out.t[1] = (T)(sn * a + cs * b);
-    if (live) *(unsigned int*)ptr = out.u;
+    const long to = (long)tok * (p.D >> 1) + ch * 4;
+    const float4 cs = *(const float4*)(p.cosT + to), sn = *(const float4*)(p.sinT + to);
+    const float cv[4] = {cs.x, cs.y, cs.z, cs.w}, nv[4] = {sn.x, sn.y, sn.z, sn.w};
+    float o[8];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const float a = x[2 * q] * rr * sv[2 * q], b = x[2 * q + 1] * rr * sv[2 * q + 1];
+        o[2 * q] = cv[q] * a - nv[q] * b;
+        o[2 * q + 1] = nv[q] * a + cv[q] * b;
+    }
+    if (live) *(uint4*)ptr = pack8<T>(o);
 }
 void launch_qk_norm_rope(const QkRopeArgs& a, DType dt, hipStream_t s) {
-    const long total = (long)a.rows * 2 * a.H * (a.D / 2);
+    const long total = (long)a.rows * 2 * a.H * (a.D / 8);
     dim3 grid((unsigned)((total + 255) / 256)), block(256);
     if (dt == DT_BF16) hipLaunchKernelGGL((qk_norm_rope_kernel<__bf16>), grid, block, 0, s, a);
     else hipLaunchKernelGGL((qk_norm_rope_kernel<_Float16>), grid, block, 0, s, a);
