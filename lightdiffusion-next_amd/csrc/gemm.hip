@@ -343,6 +343,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 struct TileSel { int bm, bn; };
 static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     if (geglu) return {128, 128};
+    static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;      // experiment switch: BM*1000+BN
+    if (force) return {force / 1000, force % 1000};
     if (N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
     if (N <= 64 && splitk <= 1 && (long)((M + 127) / 128) >= 400) return {128, 64};
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
