@@ -28,17 +28,22 @@ template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 
 // BM x BN workgroup tile, 4 waves as 2x2, each wave (BM/2) x (BN/2) = MI x NJ MFMA tiles of 16x16.
 // 128x128 / 128x160 for large problems; 64x64 for short-K problems whose 128-wide tiling would leave most CUs
 // idle (they are latency-bound: 4-5x more, smaller workgroups hide the HBM/L2 latency with thread-level parallelism).
-template <typename T, int MODE, int BM, int BN>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
-    constexpr int MI = BM / 32;                 // 16-row MFMA tiles per wave
-    constexpr int NJ = BN / 32;                 // 16-column MFMA tiles per wave
+// WM = waves along M (2: 4 waves / 256 threads, two workgroups per CU; 4: 8 waves / 512 threads with a 256-row tile, one
+// workgroup per CU — 25 % fewer L2->LDS bytes per flop for the large-M problems that are bound by that traffic).
+template <typename T, int MODE, int BM, int BN, int WM = 2>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
+    constexpr int NT = WM * 128;                // threads
+    constexpr int RPP = NT / 8;                 // tile rows staged per pass (8 threads x 16 B per 128-B row)
+    constexpr int LA = BM / RPP, LB = (BN + RPP - 1) / RPP;   // staging chunks per thread (A rows, W rows; BN = 160 at 64 rows per pass is ragged)
+    constexpr int MI = BM / WM / 16;            // 16-row MFMA tiles per wave
+    constexpr int NJ = BN / 2 / 16;             // 16-column MFMA tiles per wave
     constexpr int STAGE_BYTES = stage_bytes<BM, BN>();
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 1, wn = wave & 1;     // wm in [0, WM)
     const int l15 = lane & 15, g4 = lane >> 4;
 
     const int tiles_n = (p.N + BN - 1) / BN;   // BN = template tile width
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     // byte offsets are loop-invariant (plain GEMM) or change only when the 3x3 tap changes (conv), and rows
     // outside M / N / the zero-padding halo use an out-of-range offset, which the hardware returns as 0 —
     // no exec-mask branches, no 64-bit address arithmetic in the K loop.
-    const int srow = tid >> 3;        // 0..31 (+32*j)
+    const int srow = tid >> 3;        // 0..RPP-1 (+RPP*j)
     const int schunk = tid & 7;       // 16-B chunk within the 128-B K-slice
     constexpr int OOB = (int)0x80000000;
     const T* __restrict__ Ap = (const T*)p.A;
@@ -81,15 +86,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ap + a_base), 0, (int)(a_rem > 0x7fffffffL ? 0x7fffffffL : a_rem), 0x00020000);
     const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.K), 0, (int)(w_rem > 0x7fffffffL ? 0x7fffffffL : w_rem), 0x00020000);
 
-    int a_voff[MI];                   // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
-    int a_pix[MI];                    // conv: byte offset of this row's batch image + chunk
-    int a_oy[MI], a_ox[MI];
+    int a_voff[LA];                   // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
+    int a_pix[LA];                    // conv: byte offset of this row's batch image + chunk
+    int a_oy[LA], a_ox[LA];
 #pragma unroll
-    for (int j = 0; j < MI; ++j) {
-        const int m = m0 + srow + 32 * j;
+    for (int j = 0; j < LA; ++j) {
+        const int m = m0 + srow + RPP * j;
         const bool ok = m < p.M;
         if (MODE == 0) {
-            a_voff[j] = ok ? ((srow + 32 * j) * p.lda + schunk * 8) * 2 : OOB;
+            a_voff[j] = ok ? ((srow + RPP * j) * p.lda + schunk * 8) * 2 : OOB;
             a_pix[j] = a_oy[j] = a_ox[j] = 0;
         } else {
             const int b = m / hw, rem = m - b * hw;
@@ -100,16 +105,16 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             a_voff[j] = OOB;
         }
     }
-    int w_voff[NJ];
+    int w_voff[LB];
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-        const int n = n0 + srow + 32 * j;
-        w_voff[j] = n < p.N ? ((srow + 32 * j) * p.K + schunk * 8) * 2 : OOB;
+    for (int j = 0; j < LB; ++j) {
+        const int n = n0 + srow + RPP * j;
+        w_voff[j] = (n < p.N && srow + RPP * j < BN) ? ((srow + RPP * j) * p.K + schunk * 8) * 2 : OOB;
     }
     const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
     const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
 
-    uint4 ra[MI], rb[NJ];
+    uint4 ra[LA], rb[LB];
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
     bool st_new_tap = true;
     if (MODE == 1 && kt_begin > 0) {
@@ -126,11 +131,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         const bool kdead = (k0 + BK > p.K) && (k0 + schunk * 8 >= p.K);
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < MI; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
+            for (int j = 0; j < LA; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
         } else {
             if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll
-                for (int j = 0; j < MI; ++j) {
+                for (int j = 0; j < LA; ++j) {
                     int iy = a_oy[j] + st_ky, ix = a_ox[j] + st_kx;
                     const bool ok = a_pix[j] != OOB && iy >= 0 && iy < p.Hv && ix >= 0 && ix < p.Wv;
                     if (p.resize) {   // nearest: src = min(floor(dst * in/out), in-1)  (torch upsample_nearest)
@@ -142,23 +147,23 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             }
             const int soff = st_ci * 2;
 #pragma unroll
-            for (int j = 0; j < MI; ++j) ra[j] = ld128(rA, a_voff[j], soff);
+            for (int j = 0; j < LA; ++j) ra[j] = ld128(rA, a_voff[j], soff);
             st_ci += BK;
             st_new_tap = false;
             if (st_ci >= p.Cin) { st_ci = 0; st_new_tap = true; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
         }
 #pragma unroll
-        for (int j = 0; j < NJ; ++j) rb[j] = ld128(rW, kdead ? OOB : w_voff[j], k0 * 2);
+        for (int j = 0; j < LB; ++j) rb[j] = ld128(rW, kdead ? OOB : w_voff[j], k0 * 2);
     };
     auto lstore = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;
         char* sB = sA + BM * BK * 2;
 #pragma unroll
         for (int j = 0; j < (MI > NJ ? MI : NJ); ++j) {
-            const int row = srow + 32 * j;
+            const int row = srow + RPP * j;
             const int off = row * 128 + ((schunk ^ (row & 7)) << 4);
-            if (j < MI) *(uint4*)(sA + off) = ra[j < MI ? j : 0];
-            if (j < NJ) *(uint4*)(sB + off) = rb[j < NJ ? j : 0];
+            if (j < LA) *(uint4*)(sA + off) = ra[j < LA ? j : 0];
+            if (j < LB && (BN % RPP == 0 || row < BN)) *(uint4*)(sB + off) = rb[j < LB ? j : 0];
         }
     };
 
@@ -183,7 +188,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             V8 af[MI], bf[NJ];
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
-                const int row = wm * (BM / 2) + i * 16 + l15;
+                const int row = wm * (BM / WM) + i * 16 + l15;
                 const int ch = (ks * 4 + g4) ^ (row & 7);
                 af[i] = as_v8<T>(*(const uint4*)(sA + row * 128 + (ch << 4)));
             }
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
         float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+            const int m = m0 + wm * (BM / WM) + i * 16 + l15;
             if (m >= p.M) continue;
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -223,11 +228,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
     T* __restrict__ Cp = (T*)p.C;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / 2) + i * 16 + l15;
+        const int m = m0 + wm * (BM / WM) + i * 16 + l15;
         if (m >= p.M) continue;
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
         const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
-        if (BN != 128 || BM != 128 || !p.geglu) {
+        if (BN != 128 || !p.geglu) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
@@ -271,7 +276,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                     }
                 }
             }
-        } else if (BN == 128 && BM == 128) {
+        } else if (BN == 128) {
             // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
@@ -280,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
                 if (ng >= p.N) continue;
                 const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                constexpr int JG = (BN == 128 && BM == 128) ? 2 : 0;
+                constexpr int JG = (BN == 128) ? 2 : 0;
                 float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
                 if (p.bias) {
                     const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
@@ -342,11 +347,24 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 // tile selection: {BM, BN}
 struct TileSel { int bm, bn; };
 static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
-    if (geglu) return {128, 128};
     static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;      // experiment switch: BM*1000+BN
     if (force) return {force / 1000, force % 1000};
-    if (N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
-    if (N <= 64 && splitk <= 1 && (long)((M + 127) / 128) >= 400) return {128, 64};
+    if (!geglu && N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
+    if (!geglu && N <= 64 && splitk <= 1 && (long)((M + 127) / 128) >= 400) return {128, 64};
+    // Large-M problems: 256-row tiles on 8 waves (one workgroup per CU) move 25-35 % fewer L2->LDS bytes per flop, which is
+    // what bounds the 128-row kernel there.  Needs about a full round of 256 workgroups and a well-filled last round.
+    // Measured: +8..17 % on isolated large GEMMs / convs (operands L2/MALL-resident), but -2 % (Flux forward) to -6 % (VAE decode)
+    // in the real launch sequences, where one workgroup per CU overlaps kernel tails worse: opt-in (LDX_TILE256=1).
+    static const bool use256 = getenv("LDX_TILE256") != nullptr;
+    if (use256 && splitk <= 1 && M >= 2048 && !(geglu && K < 1024)) {
+        const long mt = (M + 255) / 256;
+        auto eff = [&](int bn) { const long t = mt * ((N + bn - 1) / bn); return t < 230 ? 0.0 : (double)t / (double)(((t + 255) / 256) * 256); };
+        const double e128 = eff(128), e160 = geglu ? 0.0 : eff(160);
+        const double waste160 = (double)(((N + 159) / 160) * 160 - N) / (double)N;
+        const bool use160 = e160 > 0.0 && waste160 <= 0.05 && e160 >= e128 - 0.08;
+        if ((use160 ? e160 : e128) >= 0.78) return {256, use160 ? 160 : 128};
+    }
+    if (geglu) return {128, 128};
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     // wave quantisation: 257..511 tiles of 128x128 put two workgroups on some CUs and one on the rest (the launch takes as
     // long as the doubly-loaded CUs); if 128x160 tiles fit one per CU, every CU runs a single, 1.25x larger tile instead
@@ -362,19 +380,21 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     return {128, bn};
 }
 
-template <typename T, int MODE, int BM, int BN>
+template <typename T, int MODE, int BM, int BN, int WM = 2>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * stage_bytes<BM, BN>();
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN>), dim3(tiles), dim3(256), lds, s, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
 template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
-    if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
+    if (t.bm == 256 && t.bn == 160) launch_gemm_inst<T, MODE, 256, 160, 4>(a, S, s);
+    else if (t.bm == 256) launch_gemm_inst<T, MODE, 256, 128, 4>(a, S, s);
+    else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
     else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);
     else if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);
     else if (t.bn == 160) launch_gemm_inst<T, MODE, 128, 160>(a, S, s);
