@@ -415,12 +415,14 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 // heuristic shared with the planner: how many K splits for an (M, N, K) problem
 int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     if (geglu) return 1;
+    static const int force_sk = getenv("LDX_SPLITK") ? atoi(getenv("LDX_SPLITK")) : 0;      // experiment switch
+    if (force_sk && K % BK == 0 && K / BK >= force_sk * 2) return force_sk;
     const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
     const int nk = K / BK;
     // a split costs a second (reduce) launch of ~9 us: only worth it for long K (3x3 convs, FF down-projection)
     if (tiles >= 200 || nk < 40 || K % BK) return 1;
-    int s = 560 / tiles;
+    int s = (440 + tiles / 2) / tiles;        // ~400-480 workgroups: 40 tiles -> 11 (measured best 10), 160 tiles -> 3
     if (s > nk / 5) s = nk / 5;
     if (s > 16) s = 16;
     return s < 2 ? 1 : s;
