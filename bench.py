@@ -11,9 +11,11 @@ N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank d
 closes the timed region (north_star: "all-gather of decoded latents only").
 
 Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline     — dominant kernel class (largest share of step time), algorithmic FLOP/s from per-op HIP events
-                 recorded on the launch stream (ldx_profile), against the dense bf16 MFMA peak (2.5 PFLOP/s,
-                 MI355X_MICROARCH.md); plus whole-step achieved TFLOP/s (9.348 TFLOP/step).
+  roofline     — dominant kernel = the single (kernel, op shape) with the largest share of step time (the level-0
+                 self-attention, D = 40, 16384 tokens), algorithmic FLOP/s from per-op HIP events recorded on the launch
+                 stream (ldx_profile mode 2), against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); HBM
+                 traffic per launch from the committed PMC passes (profiles/r*/traffic.json); the per-class breakdown in
+                 `kernels`; plus whole-step achieved TFLOP/s (9.348 TFLOP/step).
   cpu_baseline — the oracle (CPU restatement, kind "port") timed on this host's cores on a bounded sample.
 """
 import argparse
@@ -132,7 +134,7 @@ def main():
     roof = None
     if rank == 0:
         eng.set_graph_mode(False)
-        eng.profile(True, reset=True)
+        eng._lib.ldx_profile(eng._h, 2, 1)            # mode 2: keyed by kernel class AND op shape
         xs = x.clone()
         nprof = 3
         for i in range(nprof):
@@ -141,28 +143,39 @@ def main():
         eng.profile(False, reset=False)
         rep = eng.profile_report()
         tot_ms = sum(v["ms"] for v in rep.values())
+        # per kernel class (shape suffix stripped) for the breakdown ...
+        cls = {}
+        for k, v in rep.items():
+            c = k.split(" ")[0]
+            e = cls.setdefault(c, {"count": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            for f in e:
+                e[f] += v[f]
         kern = {}
-        for k, v in sorted(rep.items(), key=lambda kv: -kv[1]["ms"]):
-            e = {"launches_per_step": v["count"] // nprof, "ms_per_step": round(v["ms"] / nprof, 4),
-                 "share": round(v["ms"] / tot_ms, 4)}
+        for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["ms"]):
+            e = {"launches_per_step": v["count"] // nprof, "ms_per_step": round(v["ms"] / nprof, 4), "share": round(v["ms"] / tot_ms, 4)}
             if v["flops"] > 0:
                 e["tflops"] = round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2)
             if v["bytes"] > 0 and v["ms"] > 0:
                 e["alg_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
             kern[k] = e
-        dom = next(k for k in kern if "tflops" in kern[k])
-        # HBM bytes per launch of the dominant kernel from the committed PMC passes (profiles/r*/traffic.json), if any
+        # ... and the dominant KERNEL = the single (kernel, shape) with the most time: one launch geometry, so that "per launch"
+        # flops, duration and PMC traffic all refer to the same thing (the level-0 self-attention at 1024^2)
+        dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
+        dv = rep[dom]
+        dom_tflops = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
         traffic = None
         try:
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))[-1]
-            traffic = json.load(open(tj)).get(dom, {}).get("bytes")
+            traffic = json.load(open(tj)).get(dom, {}).get("bytes")      # HBM bytes per launch from the committed PMC passes
         except Exception:
             traffic = None
         step_ms_gpu = ev0.elapsed_time(ev1) / args.steps
-        roof = {"bound": "mfma", "kernel": dom, "achieved": kern[dom]["tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(kern[dom]["tflops"] / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
-                "avg_launch_ms": round(kern[dom]["ms_per_step"] / max(kern[dom]["launches_per_step"], 1), 4),
+        roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+                "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "launches_per_step": dv["count"] // nprof, "avg_launch_ms": round(dv["ms"] / dv["count"], 4),
+                "flop_per_launch": round(dv["flops"] / dv["count"] / 1e9, 2),
+                "share_of_step": round(dv["ms"] / tot_ms, 4),
                 "step_tflop": round(info["flops"] / 1e12, 4),
                 "step_achieved": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12, 2),
                 "step_frac": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
