@@ -247,9 +247,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
                     const float e = __builtin_amdgcn_exp2f(fmaf(s[qt][t][r], c, -mc));
                     pv[t][r] = e;
                 }
+            // the running maximum settles after the first few key blocks: skip the rescale of O^T (DT x 4 multiplies per lane)
+            // whenever no query of this wave moved its maximum (alpha == 1 everywhere) — exact, wave-uniform branch
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) {
-                o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
+                for (int dt = 0; dt < DT; ++dt) {
+                    o[qt][dt][0] *= alpha; o[qt][dt][1] *= alpha; o[qt][dt][2] *= alpha; o[qt][dt][3] *= alpha;
+                }
             }
 #pragma unroll
             for (int ks2 = 0; ks2 < 2; ++ks2) {
