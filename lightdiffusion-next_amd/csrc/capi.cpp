@@ -298,7 +298,7 @@ int ldx_op_groupnorm(const void* X, int ldx_, void* Y, int ldy, int B, int HW, i
     return check_launch("ldx_op_groupnorm");
 }
 int ldx_op_layernorm(const void* X, int ldx_, void* Y, int ldy, int rows, int C, float eps, const float* gamma, const float* beta, int dtype, void* stream) {
-    if (!X || !Y || !gamma || !beta || C % 8 || C > 3072) { set_error("ldx_op_layernorm: bad argument (C % 8, C <= 3072)"); return LDX_EINVAL; }
+    if (!X || !Y || !gamma || !beta || C % 8 || C > 4096) { set_error("ldx_op_layernorm: bad argument (C % 8, C <= 4096)"); return LDX_EINVAL; }
     LayerNormArgs a{X, ldx_, Y, ldy, rows, C, eps, gamma, beta};
     launch_layernorm(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_layernorm");
