@@ -63,6 +63,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--latent", type=int, default=128)
+    ap.add_argument("--batch", type=int, default=1, help="images per GPU (default 1 = the headline config; 8 = the per-GPU shard of SURVEY config 3)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet config")
@@ -97,9 +98,10 @@ def main():
     g = torch.Generator().manual_seed(7)
     pos = torch.randn([1, 77, cfg.context_dim], generator=g)
     neg = torch.randn([1, 77, cfg.context_dim], generator=g)
-    noise = ldx.parallel.shard_noise((world, 4, lat, lat), 42, rank, world)                   # config-3 style shard
+    pb = args.batch
+    noise = ldx.parallel.shard_noise((world * pb, 4, lat, lat), 42, rank, world)              # config-3 style shard
     x = (noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)).to(dev)
-    model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, 1, lat, lat)
+    model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, pb, lat, lat)
 
     def run_steps(i0, n):
         for i in range(i0, i0 + n):
@@ -116,7 +118,7 @@ def main():
     ev0.record()
     run_steps(args.warmup, args.steps)
     gathered = ldx.parallel.gather_latents(x, world, dist)    # final latents only: the job's single collective
-    assert gathered.shape[0] == world
+    assert gathered.shape[0] == world * pb
     ev1.record()
     torch.cuda.synchronize()
     if dist:
@@ -186,16 +188,17 @@ def main():
         cpu = cpu_baseline(cfg, sd)
 
     if rank == 0:
-        value = world * args.steps / elapsed
+        value = world * args.steps / elapsed          # sampler iterations per second (each iteration advances `batch` images per GPU)
         line = {
             "metric": "sampler it/s (UNet steps/sec) SD1.5 1024x1024 bs=1 bf16",
             "value": round(value, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": (round(value / 2.8, 3) if world == 1 else None), "dtype": args.dtype, "data": "synthetic",
             "config": {"workload": f"SD1.5 UNet (859.5M params, synthetic seeded weights) sampler loop, latent "
-                                   f"[1,4,{lat},{lat}] ({lat * 8}x{lat * 8}), CFG batch 2, ctx 77x768, sample_euler/normal, "
-                                   f"multiscale off; per-GPU bs=1, {world} image(s) in flight",
-                       "global_batch": world, "parallelism": f"batch-shard x{world} (replicated weights, final all-gather)",
+                                   f"[{pb},4,{lat},{lat}] ({lat * 8}x{lat * 8}), CFG batch {2 * pb}, ctx 77x768, sample_euler/normal, "
+                                   f"multiscale off; per-GPU bs={pb}, {world * pb} image(s) in flight",
+                       "global_batch": world * pb, "images_per_gpu": pb, "image_steps_per_s": round(world * pb * args.steps / elapsed, 3),
+                       "parallelism": f"batch-shard x{world} (replicated weights, final all-gather)",
                        "launches_per_step": info["launches"], "hip_graph": not args.no_graph,
                        "vs_baseline_note": "2.8 it/s = README table, RTX 3060 mobile + Stable-Fast (BASELINE.md §1)"},
             "roofline": roof, "cpu_baseline": cpu,
