@@ -22,6 +22,7 @@
 // Workgroup = 4 waves x 32 queries; K and V^T tiles of 64 keys double-buffered in LDS, global
 // loads register-staged one block ahead.  Head dims D in {8..160}, D % 8 == 0: the QK^T
 // contraction is padded to 32*KS, the PV output to 16*DT rows (zero-filled in LDS/registers).
+#include <stdlib.h>
 #include "ldx_device.h"
 #include "ldx_kernels.h"
 
@@ -305,6 +306,226 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// 32x32x16 variant for 32 < D <= 48 (SD1.5 level 0: D = 40, the largest kernel of a step).  On gfx950 the 16x16x32 MFMA
+// issues every ~21.5 cycles (75 % of peak) while 32x32x16 issues every 32.4 cycles for twice the work (profiles/ubench/
+// mfma_rate.hip), and at D = 40 the 16x16x32 QK^T pads the contraction to 64.  Here QK^T contracts over 48 (3 k-steps of 16):
+// 12 MFMAs per 64 keys x 64 queries instead of 32, PV 16 instead of 24 — 907 instead of 1204 issue cycles per key block.
+//
+// Same transposed formulation: S^T[key][q] and O^T[d][q], so lane l owns query l & 31 of a 32-query tile (both halves of the
+// wave hold the same queries, different keys / d rows) and the softmax state is lane-local up to one permlane32 exchange.
+// C layout of a 32x32 tile: lane l holds column l & 31, rows 8*(r>>2) + 4*(l>>5) + (r&3), r = 0..15.  Feeding S^T registers
+// 8*(s&1)..+7 of key tile s>>1 straight back as the P^T operand of k-step s makes k-slot 8h+e stand for key
+// 16s + (e < 4 ? 4h + e : 8 + 4h + e - 4); the V^T operand is gathered in exactly that order by two ds_read_b64_tr_b16 per
+// 16-lane group (keys 16s + 4h + 0..3 and 16s + 8 + 4h + 0..3, 16 d columns each).
+template <typename T>
+__global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
+    constexpr int QW = 64, QB = 256;                 // queries per wave / workgroup
+    constexpr int ROWB = 160;                        // K and V rows: 48 / 64 (+ones) 16-bit values, padded; 160 = 32 (mod 64)
+    constexpr int KBYTES = AT_KV * ROWB, STAGE = 2 * KBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V8 = typename Vec<T>::v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h2 = lane >> 5, l15 = lane & 15, g16 = lane >> 4;
+    const int nqb = (p.Nq + QB - 1) / QB;
+    const int lin = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int qblk = lin % nqb, hb = lin / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qblk * QB + wave * QW;
+    const int D = p.D, dch = D >> 3;
+    const T* __restrict__ Qp = (const T*)p.Q + (long)b * p.Nq * p.ldq + h * D;
+    const T* __restrict__ Kp = (const T*)p.K + (long)b * p.Mk * p.ldk + h * D;
+    const T* __restrict__ Vp = (const T*)p.V + (long)b * p.Mk * p.ldv + h * D;
+    T* __restrict__ Op = (T*)p.O + (long)b * p.Nq * p.ldo + h * D;
+    const float c = p.scale * 1.44269504088896340736f;
+
+    for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * ROWB + D * 2) = (T)1.0f;       // ones column of V at d = D
+
+    // Q fragments (B operand): lane holds q = l31, d = 16*ks + 8*h2 .. +7
+    V8 qf[2][3];
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int ch = 2 * ks + h2;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            qf[qt][ks] = as_v8<T>(u);
+        }
+    }
+    f32x16 o[2][2];                                  // [q tile][d tile of 32]
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    o[0][0] = zero16; o[0][1] = zero16; o[1][0] = zero16; o[1][1] = zero16;
+    float mrun[2] = {-INFINITY, -INFINITY};
+    const int nblk = (p.Mk + AT_KV - 1) / AT_KV;
+
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
+    constexpr int NLD = (AT_KV * 6 + 255) / 256;     // up to 6 chunks per row (D <= 48)
+    uint4 rk[NLD], rv[NLD];
+    int ko[NLD], vo[NLD], lo[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / dch, ch = idx - row * dch;
+        const bool in_tile = row < AT_KV;
+        ko[i] = in_tile ? (row * p.ldk + ch * 8) * 2 : OOB;
+        vo[i] = in_tile ? (row * p.ldv + ch * 8) * 2 : OOB;
+        lo[i] = in_tile ? row * ROWB + ch * 16 : -1;
+    }
+    const int kstep = AT_KV * p.ldk * 2, vstep = AT_KV * p.ldv * 2;
+    auto gload = [&](int blk) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool live = ko[i] != OOB;
+            const auto a = __builtin_amdgcn_raw_buffer_load_b128(rK, live ? ko[i] + blk * kstep : OOB, 0, 0);
+            const auto c2 = __builtin_amdgcn_raw_buffer_load_b128(rV, live ? vo[i] + blk * vstep : OOB, 0, 0);
+            rk[i] = make_uint4(a[0], a[1], a[2], a[3]);
+            rv[i] = make_uint4(c2[0], c2[1], c2[2], c2[3]);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* sB = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (lo[i] >= 0) { *(uint4*)(sB + lo[i]) = rk[i]; *(uint4*)(sB + KBYTES + lo[i]) = rv[i]; }
+    };
+
+    __syncthreads();
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        const bool more = (blk + 1) < nblk;
+        if (more) gload(blk + 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + KBYTES;
+        const int kv0 = blk * AT_KV;
+
+        // ---- S^T = K Q^T : 2 key tiles x 2 query tiles x 3 k-steps ----
+        f32x16 s[2][2];                              // [key tile][q tile]
+        s[0][0] = zero16; s[0][1] = zero16; s[1][0] = zero16; s[1][1] = zero16;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const V8 kf = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * ROWB + (2 * ks + h2) * 16));
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) s[kt][qt] = mfma32(kf, qf[qt][ks], s[kt][qt]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+
+        // scores as plain scalars from here on (element writes into a 16-wide vector made hipcc route it through scratch)
+        float sv[2][2][16];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[kt][qt][r] = s[kt][qt][r];
+        if (kv0 + AT_KV > p.Mk) {                    // ragged last key block (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + kt * 32 + 8 * (r >> 2) + 4 * h2 + (r & 3);
+                    if (kv >= p.Mk) { sv[kt][0][r] = -INFINITY; sv[kt][1][r] = -INFINITY; }
+                }
+            asm volatile("" ::: "memory");           // keep this a branch: if-conversion would run 64 selects every key block
+        }
+
+        // ---- online softmax; P packed as B-operand fragments: k-step st takes registers 8*(st&1)..+7 of key tile st>>1 ----
+        V8 pf[2][4];
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            float mx = sv[0][qt][0];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sv[kt][qt][r]);
+            {   // the other half of the wave holds the other 32 keys of the same query
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] * c - mc);
+            mrun[qt] = mnew;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+                o[qt][0] = o[qt][0] * alpha;         // whole-vector scale: no element inserts
+                o[qt][1] = o[qt][1] * alpha;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                V8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (T)__builtin_amdgcn_exp2f(fmaf(sv[st >> 1][qt][8 * (st & 1) + e], c, -mc));
+                pf[qt][st] = f;
+            }
+        }
+
+        // ---- O^T += V^T P^T : per k-step and d tile one V^T fragment (two transposing reads), used by both query tiles ----
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int dt = 0; dt < 2; ++dt) {
+                // 16-lane group g16: h' = g16 >> 1, d columns dt*32 + 16*(g16 & 1) + 0..15; lane i of the group addresses 4 contiguous d
+                // of key (i >> 2) and receives column d = .. + i for keys K0 + 0..3
+                const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * ROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
+                U128 vf;
+                vf.d[0] = lds_read_tr16(vp);
+                vf.d[1] = lds_read_tr16(vp + 8 * ROWB);
+                const V8 v8 = as_v8<T>(vf.u);
+#pragma unroll
+                for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma32(v8, pf[qt][st], o[qt][dt]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // ---- finalize: O = O^T / l ; denominator = O^T row D (the ones column of V) ----
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        // row D lives in d tile D / 32, at r with 8*(r>>2) + 4*h + (r&3) == D % 32 on the half h = ((D % 32) >> 2) & 1
+        const int dd = D & 31;
+        // 32 < D <= 48, D % 4 == 0: d tile 1, register 4*(dd>>3); selected with static indices (a runtime index would put o[] in scratch)
+        const float cand = dd < 8 ? o[qt][1][0] : (dd < 16 ? o[qt][1][4] : o[qt][1][8]);
+        const float mine = (h2 == ((dd >> 2) & 1)) ? cand : 0.f;
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+        const int q = q0 + qt * 32 + l31;
+        if (q >= p.Nq) continue;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dt * 32 + 8 * rq + 4 * h2;
+                if (d < D)
+                    *(uint2*)(Op + (long)q * p.ldo + d) = pack4<T>(o[qt][dt][4 * rq] * inv, o[qt][dt][4 * rq + 1] * inv, o[qt][dt][4 * rq + 2] * inv, o[qt][dt][4 * rq + 3] * inv);
+            }
+    }
+}
+
+template <typename T>
+static void launch_attn32(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = 2 * 2 * AT_KV * 160;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
+    hipLaunchKernelGGL((attn32_kernel<T>), grid, dim3(256), lds, s, a);
+}
+
 template <typename T, int KS, int DT, int QT>
 static void launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int STAGE = AT_KV * (AttnCfg<KS, DT>::KROWB + AttnCfg<KS, DT>::VROWB);
@@ -318,6 +539,11 @@ static void launch_attn_q(const AttnArgs& a, hipStream_t s) {
 template <typename T, int KS, int DT>
 static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
     // 64 queries per wave when the accumulators fit (DT <= 3) and the grid still fills the chip
+    if constexpr (KS == 2 && DT == 3) {
+        // D = 40 (SD1.5 level 0) on 32x32x16 MFMAs: +4.6 % in isolation, +2.2 % on the whole step; LDX_ATTN32=0 falls back
+        static const int v32 = getenv("LDX_ATTN32") ? atoi(getenv("LDX_ATTN32")) : 1;
+        if (v32 && !a.causal && !a.bias && a.D > 32 && a.D % 8 == 0 && (long)((a.Nq + 255) / 256) * a.H * a.B >= 512) { launch_attn32<T>(a, s); return; }
+    }
     if constexpr (DT <= 3) {
         if ((long)((a.Nq + 255) / 256) * a.H * a.B >= 512 && !a.causal) { launch_attn_q<T, KS, DT, 4>(a, s); return; }
     }

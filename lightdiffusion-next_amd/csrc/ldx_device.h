@@ -10,6 +10,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16   bf16x4;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4;
 typedef __attribute__((ext_vector_type(4))) float    f32x4;
+typedef __attribute__((ext_vector_type(16))) float   f32x16;
 
 template <typename T> struct Vec;
 template <> struct Vec<__bf16>   { using v8 = bf16x8; using v4 = bf16x4; };
@@ -22,6 +23,16 @@ __device__ __forceinline__ f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) {
 }
 __device__ __forceinline__ f32x4 mfma16(f16x8 a, f16x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+
+// D(32x32 f32) += A(32x16) * B(16x32).  Lane l supplies A[i = l&31][k = 8*(l>>5) + 0..7] and B[k = 8*(l>>5) + 0..7][j = l&31];
+// result lane l holds D[i = 8*(r>>2) + 4*(l>>5) + (r&3)][j = l&31], r = 0..15.  Issues every 32.4 cycles = the full 2.5 PFLOP/s,
+// whereas 16x16x32 issues every 21.5 cycles (75 %) — profiles/ubench/mfma_rate.hip.
+__device__ __forceinline__ f32x16 mfma32(bf16x8 a, bf16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
 union U128 {
