@@ -319,11 +319,11 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 // 8*(s&1)..+7 of key tile s>>1 straight back as the P^T operand of k-step s makes k-slot 8h+e stand for key
 // 16s + (e < 4 ? 4h + e : 8 + 4h + e - 4); the V^T operand is gathered in exactly that order by two ds_read_b64_tr_b16 per
 // 16-lane group (keys 16s + 4h + 0..3 and 16s + 8 + 4h + 0..3, 16 d columns each).
-template <typename T>
+template <typename T, int KVB>       // KVB keys per LDS stage (64 or 128): one barrier + one staging round per KVB keys
 __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     constexpr int QW = 64, QB = 256;                 // queries per wave / workgroup
     constexpr int ROWB = 160;                        // K and V rows: 48 / 64 (+ones) 16-bit values, padded; 160 = 32 (mod 64)
-    constexpr int KBYTES = AT_KV * ROWB, STAGE = 2 * KBYTES;
+    constexpr int KBYTES = KVB * ROWB, STAGE = 2 * KBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
 
     for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * ROWB + D * 2) = (T)1.0f;       // ones column of V at d = D
+    for (int i = tid; i < 2 * KVB; i += 256) *(T*)(smem + (i / KVB) * STAGE + KBYTES + (i % KVB) * ROWB + D * 2) = (T)1.0f;       // ones column of V at d = D
 
     // Q fragments (B operand): lane holds q = l31, d = 16*ks + 8*h2 .. +7
     V8 qf[2][3];
@@ -361,24 +361,24 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     o[0][0] = zero16; o[0][1] = zero16; o[1][0] = zero16; o[1][1] = zero16;
     float mrun[2] = {-INFINITY, -INFINITY};
-    const int nblk = (p.Mk + AT_KV - 1) / AT_KV;
+    const int nblk = (p.Mk + KVB - 1) / KVB;
 
     constexpr int OOB = (int)0x80000000;
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
-    constexpr int NLD = (AT_KV * 6 + 255) / 256;     // up to 6 chunks per row (D <= 48)
+    constexpr int NLD = (KVB * 6 + 255) / 256;       // up to 6 chunks per row (D <= 48)
     uint4 rk[NLD], rv[NLD];
     int ko[NLD], vo[NLD], lo[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int idx = tid + i * 256;
         const int row = idx / dch, ch = idx - row * dch;
-        const bool in_tile = row < AT_KV;
+        const bool in_tile = row < KVB;
         ko[i] = in_tile ? (row * p.ldk + ch * 8) * 2 : OOB;
         vo[i] = in_tile ? (row * p.ldv + ch * 8) * 2 : OOB;
         lo[i] = in_tile ? row * ROWB + ch * 16 : -1;
     }
-    const int kstep = AT_KV * p.ldk * 2, vstep = AT_KV * p.ldv * 2;
+    const int kstep = KVB * p.ldk * 2, vstep = KVB * p.ldv * 2;
     auto gload = [&](int blk) {
 #pragma unroll
         for (int i = 0; i < NLD; ++i) {
@@ -404,9 +404,10 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         const int cur = blk & 1;
         const bool more = (blk + 1) < nblk;
         if (more) gload(blk + 1);
-        const char* sK = smem + cur * STAGE;
-        const char* sV = sK + KBYTES;
-        const int kv0 = blk * AT_KV;
+        auto process = [&](const int sub) __attribute__((always_inline)) {
+        const char* sK = smem + cur * STAGE + sub * 64 * ROWB;
+        const char* sV = smem + cur * STAGE + KBYTES + sub * 64 * ROWB;
+        const int kv0 = blk * KVB + sub * 64;
 
         // ---- S^T = K Q^T : 2 key tiles x 2 query tiles x 3 k-steps ----
         f32x16 s[2][2];                              // [key tile][q tile]
@@ -430,7 +431,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
             for (int qt = 0; qt < 2; ++qt)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) sv[kt][qt][r] = s[kt][qt][r];
-        if (kv0 + AT_KV > p.Mk) {                    // ragged last key block (wave-uniform branch)
+        if (kv0 + 64 > p.Mk) {                       // ragged last key block (wave-uniform branch)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
@@ -488,6 +489,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma32(v8, pf[qt][st], o[qt][dt]);
             }
         __builtin_amdgcn_s_setprio(0);
+        };
+        process(0);
+        if (KVB == 128 && blk * KVB + 64 < p.Mk) process(1);
 
         if (more) lstore(cur ^ 1);
         __syncthreads();
@@ -517,13 +521,18 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     }
 }
 
+template <typename T, int KVB>
+static void launch_attn32_k(const AttnArgs& a, hipStream_t s) {
+    const size_t lds = 2 * 2 * KVB * 160;
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T, KVB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
+    hipLaunchKernelGGL((attn32_kernel<T, KVB>), grid, dim3(256), lds, s, a);
+}
 template <typename T>
 static void launch_attn32(const AttnArgs& a, hipStream_t s) {
-    const size_t lds = 2 * 2 * AT_KV * 160;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
-    hipLaunchKernelGGL((attn32_kernel<T>), grid, dim3(256), lds, s, a);
+    static const int kvb = getenv("LDX_ATTN32_KVB") ? atoi(getenv("LDX_ATTN32_KVB")) : 64;       // experiment switch
+    if (kvb == 128 && a.Mk >= 1024) launch_attn32_k<T, 128>(a, s); else launch_attn32_k<T, 64>(a, s);
 }
 
 template <typename T, int KS, int DT, int QT>
