@@ -11,10 +11,11 @@ Layout:
   sampling.py  host mirror of src/sample (schedulers, CFG batching, Euler / DPM++ loops)
   parallel.py  batch shard + single all-gather across the GPUs of a node (RCCL / gloo)
   weights.py   SD1.5 state-dict layout + seeded synthetic weights (no checkpoints offline)
+  checkpoint.py  load-time ingestion: checkpoint split, UNet layout sniffing, LoRA key maps + merge
 """
 from . import lib, weights  # noqa: F401
 from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine, FluxEngine, T5Engine, ESRGANEngine, bislerp, latent_upscale  # noqa: F401
 VAEEngine = VAEDecoderEngine      # the same engine encodes when encoder.* weights are loaded
 from .weights import VAEConfig, CLIPConfig, FluxConfig, T5Config, ESRGANConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
-from . import sampling, parallel  # noqa: F401
+from . import sampling, parallel, checkpoint  # noqa: F401
