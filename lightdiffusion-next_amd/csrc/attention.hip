@@ -535,6 +535,247 @@ static void launch_attn32(const AttnArgs& a, hipStream_t s) {
     if (kvb == 128 && a.Mk >= 1024) launch_attn32_k<T, 128>(a, s); else launch_attn32_k<T, 64>(a, s);
 }
 
+
+// Generalisation of attn32_kernel to the other head dims of the path (D = 64 CLIP/T5-sized, 80 and 160 for SD1.5 levels 1-3,
+// 128 for Flux): NKS k-steps of 16 over D (<= 16*NKS), NDT d-tiles of 32 holding D + 1 rows (the +1 is the ones row), QT query
+// tiles of 32 per wave.  Same register recycling S^T -> P^T and the same V^T gather; K rows are padded to an odd multiple of 32 B
+// and V rows to 64*NDT + 32 B so that both fragment reads stay bank-conflict free.
+template <typename T, int NKS, int NDT, int QT>
+__global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
+    constexpr int QW = 32 * QT, QB = 4 * QW;
+    constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32;
+    constexpr int VROW = NDT * 64 + 32;
+    constexpr int KBYTES = AT_KV * KROW, VBYTES = AT_KV * VROW, STAGE = KBYTES + VBYTES;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    using V8 = typename Vec<T>::v8;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, h2 = lane >> 5, l15 = lane & 15, g16 = lane >> 4;
+    const int nqb = (p.Nq + QB - 1) / QB;
+    const int lin = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int qblk = lin % nqb, hb = lin / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qblk * QB + wave * QW;
+    const int D = p.D, dch = D >> 3;
+    const T* __restrict__ Qp = (const T*)p.Q + (long)b * p.Nq * p.ldq + h * D;
+    const T* __restrict__ Kp = (const T*)p.K + (long)b * p.Mk * p.ldk + h * D;
+    const T* __restrict__ Vp = (const T*)p.V + (long)b * p.Mk * p.ldv + h * D;
+    T* __restrict__ Op = (T*)p.O + (long)b * p.Nq * p.ldo + h * D;
+    const float c = p.scale * 1.44269504088896340736f;
+
+    for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + D * 2) = (T)1.0f;       // ones column of V at d = D
+
+    V8 qf[QT][NKS];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        const int q = q0 + qt * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) {
+            const int ch = 2 * ks + h2;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            qf[qt][ks] = as_v8<T>(u);
+        }
+    }
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 o[QT][NDT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = zero16;
+    float mrun[QT];
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) mrun[qt] = -INFINITY;
+    const int nblk = (p.Mk + AT_KV - 1) / AT_KV;
+
+    constexpr int OOB = (int)0x80000000;
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
+    constexpr int NLD = (AT_KV * NKS * 2 + 255) / 256;       // up to 2*NKS chunks per row
+    uint4 rk[NLD], rv[NLD];
+    int ko[NLD], vo[NLD], lk[NLD], lv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+        const int idx = tid + i * 256;
+        const int row = idx / dch, ch = idx - row * dch;
+        const bool in_tile = row < AT_KV;
+        ko[i] = in_tile ? (row * p.ldk + ch * 8) * 2 : OOB;
+        vo[i] = in_tile ? (row * p.ldv + ch * 8) * 2 : OOB;
+        lk[i] = in_tile ? row * KROW + ch * 16 : -1;
+        lv[i] = in_tile ? KBYTES + row * VROW + ch * 16 : -1;
+    }
+    const int kstep = AT_KV * p.ldk * 2, vstep = AT_KV * p.ldv * 2;
+    auto gload = [&](int blk) {
+#pragma unroll
+        for (int i = 0; i < NLD; ++i) {
+            const bool live = ko[i] != OOB;
+            const auto a = __builtin_amdgcn_raw_buffer_load_b128(rK, live ? ko[i] + blk * kstep : OOB, 0, 0);
+            const auto c2 = __builtin_amdgcn_raw_buffer_load_b128(rV, live ? vo[i] + blk * vstep : OOB, 0, 0);
+            rk[i] = make_uint4(a[0], a[1], a[2], a[3]);
+            rv[i] = make_uint4(c2[0], c2[1], c2[2], c2[3]);
+        }
+    };
+    auto lstore = [&](int stage) {
+        char* sB = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < NLD; ++i)
+            if (lk[i] >= 0) { *(uint4*)(sB + lk[i]) = rk[i]; *(uint4*)(sB + lv[i]) = rv[i]; }
+    };
+
+    __syncthreads();
+    if (nblk > 0) { gload(0); lstore(0); }
+    __syncthreads();
+
+    for (int blk = 0; blk < nblk; ++blk) {
+        const int cur = blk & 1;
+        const bool more = (blk + 1) < nblk;
+        if (more) gload(blk + 1);
+        const char* sK = smem + cur * STAGE;
+        const char* sV = sK + KBYTES;
+        const int kv0 = blk * AT_KV;
+
+        f32x16 s[2][QT];                             // [key tile][q tile]
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt) s[kt][qt] = zero16;
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt) {
+                const V8 kf = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * KROW + (2 * ks + h2) * 16));
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) s[kt][qt] = mfma32(kf, qf[qt][ks], s[kt][qt]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+
+        float sv[2][QT][16];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int qt = 0; qt < QT; ++qt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sv[kt][qt][r] = s[kt][qt][r];
+        if (kv0 + AT_KV > p.Mk) {                    // ragged last key block (wave-uniform branch)
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int kv = kv0 + kt * 32 + 8 * (r >> 2) + 4 * h2 + (r & 3);
+                    if (kv >= p.Mk) {
+#pragma unroll
+                        for (int qt = 0; qt < QT; ++qt) sv[kt][qt][r] = -INFINITY;
+                    }
+                }
+            asm volatile("" ::: "memory");
+        }
+
+        V8 pf[QT][4];
+#pragma unroll
+        for (int qt = 0; qt < QT; ++qt) {
+            float mx = sv[0][qt][0];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sv[kt][qt][r]);
+            {
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
+                mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+            }
+            const float mnew = fmaxf(mrun[qt], mx);
+            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;
+            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] * c - mc);
+            mrun[qt] = mnew;
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+                for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+            }
+#pragma unroll
+            for (int st = 0; st < 4; ++st) {
+                V8 f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) f[e] = (T)__builtin_amdgcn_exp2f(fmaf(sv[st >> 1][qt][8 * (st & 1) + e], c, -mc));
+                pf[qt][st] = f;
+            }
+        }
+
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int st = 0; st < 4; ++st)
+#pragma unroll
+            for (int dt = 0; dt < NDT; ++dt) {
+                const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * VROW + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
+                U128 vf;
+                vf.d[0] = lds_read_tr16(vp);
+                vf.d[1] = lds_read_tr16(vp + 8 * VROW);
+                const V8 v8 = as_v8<T>(vf.u);
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) o[qt][dt] = mfma32(v8, pf[qt][st], o[qt][dt]);
+            }
+        __builtin_amdgcn_s_setprio(0);
+
+        if (more) lstore(cur ^ 1);
+        __syncthreads();
+    }
+
+    // finalize: denominator = O^T row D: d tile D / 32, register 4*((D%32)>>3) + (D%32 & 3) on the half ((D%32)>>2)&1 — D % 8 == 0,
+    // so the register is 4*(dd>>3) and it is selected with static indices
+    const int dd = D & 31, tD = D >> 5;
+#pragma unroll
+    for (int qt = 0; qt < QT; ++qt) {
+        float cand = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt) {
+            const float c0 = o[qt][dt][0], c1 = o[qt][dt][4], c2 = o[qt][dt][8], c3 = o[qt][dt][12];
+            const float pick = (dd >> 3) == 0 ? c0 : ((dd >> 3) == 1 ? c1 : ((dd >> 3) == 2 ? c2 : c3));
+            cand = (dt == tD) ? pick : cand;
+        }
+        const float mine = (h2 == ((dd >> 2) & 1)) ? cand : 0.f;
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+        const int q = q0 + qt * 32 + l31;
+        if (q >= p.Nq) continue;
+#pragma unroll
+        for (int dt = 0; dt < NDT; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dt * 32 + 8 * rq + 4 * h2;
+                if (d < D)
+                    *(uint2*)(Op + (long)q * p.ldo + d) = pack4<T>(o[qt][dt][4 * rq] * inv, o[qt][dt][4 * rq + 1] * inv, o[qt][dt][4 * rq + 2] * inv, o[qt][dt][4 * rq + 3] * inv);
+            }
+    }
+}
+
+template <typename T, int NKS, int NDT, int QT>
+static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
+    constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32, VROW = NDT * 64 + 32;
+    const size_t lds = 2 * AT_KV * (KROW + VROW);
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32g_kernel<T, NKS, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    constexpr int QB = 128 * QT;
+    dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
+    hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT>), grid, dim3(256), lds, s, a);
+}
+// head dims served by the generic 32x32x16 kernel (LDX_ATTN32G bit mask 1: D=80, 2: D=160, 4: D=128, 8: D=64).  Default 3: same-box
+// step A/B 54.76 -> 55.34 it/s with D = 80 and 160; D = 128 (Flux) measures equal (the ones row costs a fifth d tile), D = 64 only
+// appears with a causal mask or a bias on this path.
+template <typename T>
+static bool try_attn32g(const AttnArgs& a, hipStream_t s) {
+    static const int mask = getenv("LDX_ATTN32G") ? atoi(getenv("LDX_ATTN32G")) : 3;
+    if (!mask || a.causal || a.bias) return false;
+    const long wg = (long)((a.Nq + 127) / 128) * a.H * a.B;
+    static const long min_wg = getenv("LDX_ATTN32G_MINWG") ? atol(getenv("LDX_ATTN32G_MINWG")) : 64;
+    if (wg < min_wg) return false;
+    if ((mask & 1) && a.D == 80) { launch_attn32g<T, 5, 3, 1>(a, s); return true; }
+    if ((mask & 2) && a.D == 160) { launch_attn32g<T, 10, 6, 1>(a, s); return true; }
+    if ((mask & 4) && a.D == 128) { launch_attn32g<T, 8, 5, 1>(a, s); return true; }
+    if ((mask & 8) && a.D == 64) { launch_attn32g<T, 4, 3, 1>(a, s); return true; }
+    return false;
+}
+
 template <typename T, int KS, int DT, int QT>
 static void launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int STAGE = AT_KV * (AttnCfg<KS, DT>::KROWB + AttnCfg<KS, DT>::VROWB);
@@ -562,6 +803,7 @@ static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
 template <typename T>
 static void launch_attn_d(const AttnArgs& a, hipStream_t s) {
     const int D = a.D;
+    if (try_attn32g<T>(a, s)) return;
     // KS = ceil(D/32) contraction steps, DT = floor(D/16) + 1 output tiles (room for the ones column at d = D)
     if (D < 16) launch_attn_t<T, 1, 1>(a, s);
     else if (D < 32) launch_attn_t<T, 1, 2>(a, s);
