@@ -540,7 +540,9 @@ static void launch_attn32(const AttnArgs& a, hipStream_t s) {
 // 128 for Flux): NKS k-steps of 16 over D (<= 16*NKS), NDT d-tiles of 32 holding D + 1 rows (the +1 is the ones row), QT query
 // tiles of 32 per wave.  Same register recycling S^T -> P^T and the same V^T gather; K rows are padded to an odd multiple of 32 B
 // and V rows to 64*NDT + 32 B so that both fragment reads stay bank-conflict free.
-template <typename T, int NKS, int NDT, int QT>
+// ONES: denominator from a ones column of V (row D of O^T, needs D + 1 <= 32*NDT); otherwise (D a multiple of 32: the ones row would
+// cost a whole extra d tile) the fp32 P values are summed on the VALU per lane and the two halves are added once at the end.
+template <typename T, int NKS, int NDT, int QT, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     constexpr int QW = 32 * QT, QB = 4 * QW;
     constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
 
     for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    if (tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + D * 2) = (T)1.0f;       // ones column of V at d = D
+    if (ONES && tid < 2 * AT_KV) *(T*)(smem + (tid >> 6) * STAGE + KBYTES + (tid & 63) * VROW + D * 2) = (T)1.0f;       // ones column of V at d = D
 
     V8 qf[QT][NKS];
 #pragma unroll
@@ -584,9 +586,9 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     for (int qt = 0; qt < QT; ++qt)
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = zero16;
-    float mrun[QT];
+    float mrun[QT], lsum[QT];
 #pragma unroll
-    for (int qt = 0; qt < QT; ++qt) mrun[qt] = -INFINITY;
+    for (int qt = 0; qt < QT; ++qt) { mrun[qt] = -INFINITY; lsum[qt] = 0.f; }
     const int nblk = (p.Mk + AT_KV - 1) / AT_KV;
 
     constexpr int OOB = (int)0x80000000;
@@ -691,14 +693,21 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
                 for (int dt = 0; dt < NDT; ++dt) o[qt][dt] = o[qt][dt] * alpha;
+                if (!ONES) lsum[qt] *= alpha;
             }
+            float part = 0.f;
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 V8 f;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) f[e] = (T)__builtin_amdgcn_exp2f(fmaf(sv[st >> 1][qt][8 * (st & 1) + e], c, -mc));
+                for (int e = 0; e < 8; ++e) {
+                    const float pe = __builtin_amdgcn_exp2f(fmaf(sv[st >> 1][qt][8 * (st & 1) + e], c, -mc));
+                    if (!ONES) part += pe;
+                    f[e] = (T)pe;
+                }
                 pf[qt][st] = f;
             }
+            if (!ONES) lsum[qt] += part;
         }
 
         __builtin_amdgcn_s_setprio(1);
@@ -725,14 +734,19 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     const int dd = D & 31, tD = D >> 5;
 #pragma unroll
     for (int qt = 0; qt < QT; ++qt) {
-        float cand = 0.f;
+        float mine;
+        if (ONES) {
+            float cand = 0.f;
 #pragma unroll
-        for (int dt = 0; dt < NDT; ++dt) {
-            const float c0 = o[qt][dt][0], c1 = o[qt][dt][4], c2 = o[qt][dt][8], c3 = o[qt][dt][12];
-            const float pick = (dd >> 3) == 0 ? c0 : ((dd >> 3) == 1 ? c1 : ((dd >> 3) == 2 ? c2 : c3));
-            cand = (dt == tD) ? pick : cand;
+            for (int dt = 0; dt < NDT; ++dt) {
+                const float c0 = o[qt][dt][0], c1 = o[qt][dt][4], c2 = o[qt][dt][8], c3 = o[qt][dt][12];
+                const float pick = (dd >> 3) == 0 ? c0 : ((dd >> 3) == 1 ? c1 : ((dd >> 3) == 2 ? c2 : c3));
+                cand = (dt == tD) ? pick : cand;
+            }
+            mine = (h2 == ((dd >> 2) & 1)) ? cand : 0.f;
+        } else {
+            mine = lsum[qt];                          // this half's keys; the other half of the wave holds the rest
         }
-        const float mine = (h2 == ((dd >> 2) & 1)) ? cand : 0.f;
         auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
         const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;
@@ -749,30 +763,30 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     }
 }
 
-template <typename T, int NKS, int NDT, int QT>
+template <typename T, int NKS, int NDT, int QT, bool ONES>
 static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
     constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32, VROW = NDT * 64 + 32;
     const size_t lds = 2 * AT_KV * (KROW + VROW);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32g_kernel<T, NKS, NDT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32g_kernel<T, NKS, NDT, QT, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     constexpr int QB = 128 * QT;
     dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
-    hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT, ONES>), grid, dim3(256), lds, s, a);
 }
-// head dims served by the generic 32x32x16 kernel (LDX_ATTN32G bit mask 1: D=80, 2: D=160, 4: D=128, 8: D=64).  Default 3: same-box
-// step A/B 54.76 -> 55.34 it/s with D = 80 and 160; D = 128 (Flux) measures equal (the ones row costs a fifth d tile), D = 64 only
-// appears with a causal mask or a bias on this path.
+// head dims served by the generic 32x32x16 kernel (LDX_ATTN32G bit mask 1: D=80, 2: D=160, 4: D=128, 8: D=64).  Default 7: same-box
+// step A/B 54.76 -> 55.34 it/s with D = 80 and 160; D = 128 (Flux, VALU denominator instead of a fifth d tile) 19.6 -> 18.4 ms of
+// attention per forward; D = 64 only appears with a causal mask or a bias on this path.
 template <typename T>
 static bool try_attn32g(const AttnArgs& a, hipStream_t s) {
-    static const int mask = getenv("LDX_ATTN32G") ? atoi(getenv("LDX_ATTN32G")) : 3;
+    static const int mask = getenv("LDX_ATTN32G") ? atoi(getenv("LDX_ATTN32G")) : 7;
     if (!mask || a.causal || a.bias) return false;
     const long wg = (long)((a.Nq + 127) / 128) * a.H * a.B;
     static const long min_wg = getenv("LDX_ATTN32G_MINWG") ? atol(getenv("LDX_ATTN32G_MINWG")) : 64;
     if (wg < min_wg) return false;
-    if ((mask & 1) && a.D == 80) { launch_attn32g<T, 5, 3, 1>(a, s); return true; }
-    if ((mask & 2) && a.D == 160) { launch_attn32g<T, 10, 6, 1>(a, s); return true; }
-    if ((mask & 4) && a.D == 128) { launch_attn32g<T, 8, 5, 1>(a, s); return true; }
-    if ((mask & 8) && a.D == 64) { launch_attn32g<T, 4, 3, 1>(a, s); return true; }
+    if ((mask & 1) && a.D == 80) { launch_attn32g<T, 5, 3, 1, true>(a, s); return true; }
+    if ((mask & 2) && a.D == 160) { launch_attn32g<T, 10, 6, 1, true>(a, s); return true; }
+    if ((mask & 4) && a.D == 128) { launch_attn32g<T, 8, 4, 1, false>(a, s); return true; }
+    if ((mask & 8) && a.D == 64) { launch_attn32g<T, 4, 2, 1, false>(a, s); return true; }
     return false;
 }
 

@@ -194,6 +194,7 @@ ATTN_CASES = [
     (4, 16, 2048, 333, 40, 0, 0), (8, 8, 2000, 2048, 40, 0, 0), (2, 32, 2048, 64, 40, 0, 0),
     # >= 64 workgroups of 128 queries at D = 80 / 160: the generic 32x32x16 kernel (attn32g_kernel)
     (2, 8, 1024, 1024, 160, 0, 1), (2, 8, 4096, 77, 80, 0, 0), (2, 16, 1000, 333, 80, 0, 0), (4, 8, 513, 1024, 160, 0, 0), (2, 8, 4096, 4096, 80, 0, 1),
+    (1, 24, 1100, 1100, 128, 0, 1), (2, 12, 700, 130, 128, 0, 0),       # D = 128 (Flux): VALU-denominator variant
 ]
 
 
