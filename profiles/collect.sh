@@ -19,7 +19,7 @@ fs = glob.glob("/tmp/pm/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: [0.0, set()])
 for r in csv.DictReader(open(fs[0])):
     n = r["Kernel_Name"]
-    if "ldx" in n and ("attn_kernel" in n or "gemm_kernel" in n):
+    if "ldx" in n and ("attn" in n or "gemm_kernel" in n):
         a = acc[n]; a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 for n, (v, d) in acc.items():
     print(f"{sys.argv[1]} {sys.argv[2]} per-dispatch={v/len(d):.1f} dispatches={len(d)} kernel={n[:80]}")
