@@ -239,6 +239,14 @@ int ldx_op_convert(const float* in_f32, void* out_16, int64_t n, int dtype, int 
 int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, const float* bias,
                 const float* rowvec, int rowvec_ld, int rows_per_batch, int geglu,
                 const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream);
+/* MX fp8 operands for the block-scaled MFMA (OCP microscaling: blocks of 32 consecutive k share one E8M0 scale
+ * 2^ceil(log2(amax/448)), elements are e4m3fn = x / scale rounded to nearest even; BASELINE config 4 "fp8 MFMA").
+ * ldx_op_mx_quant: 16-bit X [rows][K] (stride ldx) -> Y bytes [rows][ldy] + scales: uint32 [K/128][scales_ld], byte j of
+ * word [t][r] = scale of block 4 t + j of row r.  ldx_op_gemm_mx: C = act(A W^T + bias) (+ R) on such operands (A [M][K],
+ * W [N][K]); fp32 accumulation; act as ldx_kernels.h GemmArgs::act; outputs 16-bit C and / or fp32 Cf. */
+int ldx_op_mx_quant(const void* X, int ldx, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream);
+int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const void* W8, const void* SW, int sw_ld, int M, int N, int K,
+                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream);
 int ldx_op_conv3x3(const void* X, int ldx, const void* W, int B, int Hin, int Win, int Cin, int Cout,
                    int stride, int Hout, int Wout, int resize_to_out, const float* bias,
                    const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,

@@ -274,6 +274,29 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm");
 }
+int ldx_op_mx_quant(const void* X, int ldx_, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream) {
+    if (!X || !Y || !scales || rows <= 0 || K <= 0 || K % 128 || ldx_ % 8 || ldy % 16 || ldy < K || scales_ld < rows) {
+        set_error("ldx_op_mx_quant: bad argument (K % 128, ldx % 8, ldy % 16, scales_ld >= rows)"); return LDX_EINVAL; }
+    MxQuantArgs a{X, ldx_, rows, K, Y, ldy, (uint32_t*)scales, scales_ld};
+    launch_mx_quant(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_mx_quant");
+}
+int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const void* W8, const void* SW, int sw_ld, int M, int N, int K,
+                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream) {
+    if (!A8 || !W8 || !SA || !SW || M <= 0 || N <= 0 || K <= 0 || K % 128 || lda % 16 || sa_ld < M || sw_ld < N || (!C && !Cf) || act < 0 || act > 3) {
+        set_error("ldx_op_gemm_mx: bad argument (K % 128, lda % 16, sa_ld >= M, sw_ld >= N)"); return LDX_EINVAL; }
+    GemmArgs g{};
+    g.A = A8; g.lda = lda; g.W = W8; g.M = M; g.N = N; g.K = K; g.mode = 0; g.bias = bias; g.rows_per_batch = 1; g.act = act;
+    g.f8 = 1; g.SA = (const uint32_t*)SA; g.sa_ld = sa_ld; g.SW = (const uint32_t*)SW; g.sw_ld = sw_ld;
+    g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cf = Cf; g.ldcf = ldcf;
+    g.splitk = gemm_choose_splitk(M, N, K / 2, false);
+    if (g.splitk > 1) {
+        g.ws = op_workspace((size_t)g.splitk * M * N);
+        if (!g.ws) { set_error("split-K workspace allocation failed"); return LDX_EHIP; }
+    }
+    launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_gemm_mx");
+}
 int ldx_op_conv3x3(const void* X, int ldx_, const void* W, int B, int Hin, int Win, int Cin, int Cout, int stride, int Hout, int Wout,
                    int resize_to_out, const float* bias, const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,
                    int dtype, void* stream) {

@@ -30,8 +30,15 @@ template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 
 // idle (they are latency-bound: 4-5x more, smaller workgroups hide the HBM/L2 latency with thread-level parallelism).
 // WM = waves along M (2: 4 waves / 256 threads, two workgroups per CU; 4: 8 waves / 512 threads with a 256-row tile, one
 // workgroup per CU — 25 % fewer L2->LDS bytes per flop for the large-M problems that are bound by that traffic).
-template <typename T, int MODE, int BM, int BN, int WM = 2>
+// F8: A / W are MX fp8 bytes (GemmArgs::f8): a K-tile is still 128 B per row = 128 elements, one 16x16x128 block-scaled MFMA
+// per (i, j) and K-tile instead of two 16x16x32; the E8M0 scales bypass LDS (one dword per row and K-tile, prefetched with
+// the tile).  Same LDS layout, staging, split-K and epilogue as the 16-bit kernel.
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
+    static_assert(!F8 || MODE == 0, "MX fp8 operands: plain GEMM only");
+    constexpr int ES = F8 ? 1 : 2;              // bytes per A / W element
+    constexpr int KE = 128 / ES;                // elements per K-tile (= BK for 16-bit)
+    constexpr int CE = 16 / ES;                 // elements per 16-B staging chunk
     constexpr int NT = WM * 128;                // threads
     constexpr int RPP = NT / 8;                 // tile rows staged per pass (8 threads x 16 B per 128-B row)
     constexpr int LA = BM / RPP, LB = (BN + RPP - 1) / RPP;   // staging chunks per thread (A rows, W rows; BN = 160 at 64 rows per pass is ragged)
@@ -54,7 +61,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     const int bid = lin % ntiles, split = lin / ntiles;      // same-split tiles adjacent: neighbours share panels
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
-    const int nk_all = (p.K + BK - 1) / BK;      // K % 8 == 0; a ragged last K-tile is zero-filled by the loader
+    const int nk_all = (p.K + KE - 1) / KE;      // K % 8 == 0; a ragged last K-tile is zero-filled by the loader
     const int kt_begin = (int)((long)split * nk_all / S), kt_end = (int)((long)(split + 1) * nk_all / S);
     const int nk = kt_end - kt_begin;
 
@@ -66,8 +73,8 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     const int srow = tid >> 3;        // 0..RPP-1 (+RPP*j)
     const int schunk = tid & 7;       // 16-B chunk within the 128-B K-slice
     constexpr int OOB = (int)0x80000000;
-    const T* __restrict__ Ap = (const T*)p.A;
-    const T* __restrict__ Wp = (const T*)p.W;
+    const char* __restrict__ Ap = (const char*)p.A;
+    const char* __restrict__ Wp = (const char*)p.W;
     const int hw = (MODE == 1) ? p.Hout * p.Wout : 1;
     const int b0 = (MODE == 1) ? m0 / hw : 0;
     const long img = (long)p.Hin * p.Win * p.lda;                       // conv: elements per input image
@@ -81,10 +88,10 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     }
     const long a_base = (MODE == 0) ? (long)m0 * p.lda : (long)b0 * img + (long)row0 * p.Win * p.lda;
     const long a_total = (MODE == 0) ? (long)(p.M - 1) * p.lda + p.K : ((long)(p.M / hw) * p.Hin * p.Win - 1) * p.lda + p.Cin;
-    const long a_rem = (a_total - a_base) * 2;
-    const long w_rem = ((long)p.N * p.K - (long)n0 * p.K) * 2;
-    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ap + a_base), 0, (int)(a_rem > 0x7fffffffL ? 0x7fffffffL : a_rem), 0x00020000);
-    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.K), 0, (int)(w_rem > 0x7fffffffL ? 0x7fffffffL : w_rem), 0x00020000);
+    const long a_rem = (a_total - a_base) * ES;
+    const long w_rem = ((long)p.N * p.K - (long)n0 * p.K) * ES;
+    const __amdgpu_buffer_rsrc_t rA = __builtin_amdgcn_make_buffer_rsrc((void*)(Ap + a_base * ES), 0, (int)(a_rem > 0x7fffffffL ? 0x7fffffffL : a_rem), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rW = __builtin_amdgcn_make_buffer_rsrc((void*)(Wp + (long)n0 * p.K * ES), 0, (int)(w_rem > 0x7fffffffL ? 0x7fffffffL : w_rem), 0x00020000);
 
     int a_voff[LA];                   // plain: final byte offset ; conv: per-tap byte offset (recomputed per tap)
     int a_pix[LA];                    // conv: byte offset of this row's batch image + chunk
@@ -94,7 +101,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
         const int m = m0 + srow + RPP * j;
         const bool ok = m < p.M;
         if (MODE == 0) {
-            a_voff[j] = ok ? ((srow + RPP * j) * p.lda + schunk * 8) * 2 : OOB;
+            a_voff[j] = ok ? ((srow + RPP * j) * p.lda + schunk * CE) * ES : OOB;
             a_pix[j] = a_oy[j] = a_ox[j] = 0;
         } else {
             const int b = m / hw, rem = m - b * hw;
@@ -109,12 +116,25 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
         const int n = n0 + srow + RPP * j;
-        w_voff[j] = (n < p.N && srow + RPP * j < BN) ? ((srow + RPP * j) * p.K + schunk * 8) * 2 : OOB;
+        w_voff[j] = (n < p.N && srow + RPP * j < BN) ? ((srow + RPP * j) * p.K + schunk * CE) * ES : OOB;
     }
     const float rs_y = (MODE == 1 && p.resize) ? (float)p.Hin / (float)p.Hv : 1.f;
     const float rs_x = (MODE == 1 && p.resize) ? (float)p.Win / (float)p.Wv : 1.f;
 
     uint4 ra[LA], rb[LB];
+    // MX scales: lane (l15, g4) of tile i needs byte g4 of dword SA[kt][m0 + wm*(BM/WM) + 16 i + l15] (same for W rows)
+    uint32_t rsa[F8 ? MI : 1], rsb[F8 ? NJ : 1];
+    int sa_voff[F8 ? MI : 1], sb_voff[F8 ? NJ : 1];
+    __amdgpu_buffer_rsrc_t rSA, rSW;
+    if (F8) {
+        const long sa_rem = ((long)nk_all * p.sa_ld - m0) * 4, sw_rem = ((long)nk_all * p.sw_ld - n0) * 4;
+        rSA = __builtin_amdgcn_make_buffer_rsrc((void*)(p.SA + m0), 0, (int)(sa_rem > 0x7fffffffL ? 0x7fffffffL : sa_rem), 0x00020000);
+        rSW = __builtin_amdgcn_make_buffer_rsrc((void*)(p.SW + n0), 0, (int)(sw_rem > 0x7fffffffL ? 0x7fffffffL : sw_rem), 0x00020000);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) { const int r = wm * (BM / WM) + i * 16 + l15; sa_voff[i] = (m0 + r < p.M) ? r * 4 : OOB; }
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) { const int r = wn * (BN / 2) + j * 16 + l15; sb_voff[j] = (n0 + r < p.N) ? r * 4 : OOB; }
+    }
     int st_ky = 0, st_kx = 0, st_ci = 0;   // conv: gload() is called with kt = 0,1,2,... in order
     bool st_new_tap = true;
     if (MODE == 1 && kt_begin > 0) {
@@ -126,12 +146,18 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
         return make_uint4(v[0], v[1], v[2], v[3]);
     };
     auto gload = [&](int kt) {
-        const int k0 = (kt_begin + kt) * BK;
+        const int k0 = (kt_begin + kt) * KE;
         // ragged last K-tile (plain GEMM only; conv has K = 9*Cin, Cin % 64 == 0): chunks past K read as 0
-        const bool kdead = (k0 + BK > p.K) && (k0 + schunk * 8 >= p.K);
+        const bool kdead = (k0 + KE > p.K) && (k0 + schunk * CE >= p.K);
+        if (F8) {          // out-of-range rows read scale byte 0 (2^-127) against zero-filled operands
+#pragma unroll
+            for (int i = 0; i < MI; ++i) rsa[i] = __builtin_amdgcn_raw_buffer_load_b32(rSA, sa_voff[i], (kt_begin + kt) * p.sa_ld * 4, 0);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) rsb[j] = __builtin_amdgcn_raw_buffer_load_b32(rSW, sb_voff[j], (kt_begin + kt) * p.sw_ld * 4, 0);
+        }
         if (MODE == 0) {
 #pragma unroll
-            for (int j = 0; j < LA; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * 2);
+            for (int j = 0; j < LA; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * ES);
         } else {
             if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll
@@ -153,7 +179,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
             if (st_ci >= p.Cin) { st_ci = 0; st_new_tap = true; if (++st_kx == 3) { st_kx = 0; ++st_ky; } }
         }
 #pragma unroll
-        for (int j = 0; j < LB; ++j) rb[j] = ld128(rW, kdead ? OOB : w_voff[j], k0 * 2);
+        for (int j = 0; j < LB; ++j) rb[j] = ld128(rW, kdead ? OOB : w_voff[j], k0 * ES);
     };
     auto lstore = [&](int stage) {
         char* sA = smem + stage * STAGE_BYTES;
@@ -180,9 +206,34 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     for (int kt = 0; kt < nk; ++kt) {
         const int cur = kt & 1;
         const bool more = (kt + 1) < nk;
+        int csa[F8 ? MI : 1], csb[F8 ? NJ : 1];          // this K-tile's scales, own block's byte moved to bits 0..7
+        if (F8) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) csa[i] = (int)(rsa[i] >> (8 * g4));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) csb[j] = (int)(rsb[j] >> (8 * g4));
+        }
         if (more) gload(kt + 1);
         const char* sA = smem + cur * STAGE_BYTES;
         const char* sB = sA + BM * BK * 2;
+        if (F8) {
+            i32x8 af8[MI], bf8[NJ];
+            auto frag = [&](const char* base, int row) {
+                // operand registers 0-3 of lane group g hold k = 16 g + 0..15, registers 4-7 hold k = 64 + 16 g + 0..15, and the
+                // scale of lane group b applies to k = 32 b .. 32 b + 31 (measured: profiles/ubench/mx_layout.hip)
+                const uint4 lo = *(const uint4*)(base + row * 128 + ((g4 ^ (row & 7)) << 4));
+                const uint4 hi = *(const uint4*)(base + row * 128 + (((4 + g4) ^ (row & 7)) << 4));
+                return (i32x8){(int)lo.x, (int)lo.y, (int)lo.z, (int)lo.w, (int)hi.x, (int)hi.y, (int)hi.z, (int)hi.w};
+            };
+#pragma unroll
+            for (int i = 0; i < MI; ++i) af8[i] = frag(sA, wm * (BM / WM) + i * 16 + l15);
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) bf8[j] = frag(sB, wn * (BN / 2) + j * 16 + l15);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16_mx(bf8[j], af8[i], acc[i][j], csb[j], csa[i]);
+        } else
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
             V8 af[MI], bf[NJ];
@@ -380,17 +431,24 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     return {128, bn};
 }
 
-template <typename T, int MODE, int BM, int BN, int WM = 2>
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * stage_bytes<BM, BN>();
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN, WM>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
-    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM>), dim3(tiles), dim3(WM * 128), lds, s, a);
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN, WM, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
 template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
+    if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
+        const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S);
+        if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
+        else if (t.bn == 160) launch_gemm_inst<T, 0, 128, 160, 2, true>(a, S, s);
+        else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
+        return;
+    }
     const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
     if (t.bm == 256 && t.bn == 160) launch_gemm_inst<T, MODE, 256, 160, 4>(a, S, s);
     else if (t.bm == 256) launch_gemm_inst<T, MODE, 256, 128, 4>(a, S, s);

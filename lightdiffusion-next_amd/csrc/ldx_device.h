@@ -35,6 +35,15 @@ __device__ __forceinline__ f32x16 mfma32(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 
+// MX block-scaled fp8 (OCP e4m3fn): D(16x16 f32) += A(16x128) * B(128x16).  Lane l (i = l&15, g = l>>4) supplies 32 bytes of
+// row i: registers 0-3 = k 16g .. 16g+15, registers 4-7 = k 64+16g .. 64+16g+15 (same for B), and ONE E8M0 scale
+// (2^(s-127), low byte of sa / sb) that the hardware applies to the 32-element block k = 32g .. 32g+31 of row i — i.e. the
+// scale a lane supplies does NOT belong to the bytes it supplies (measured, profiles/ubench/mx_layout.hip).  D layout as mfma16.  Issues at twice the bf16 flop rate (the only way to the 5 PFLOP/s fp8 peak on gfx950).
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+__device__ __forceinline__ f32x4 mfma16_mx(i32x8 a, i32x8 b, f32x4 c, int sa, int sb) {
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
+}
+
 union U128 {
     uint4 u;
     bf16x8 b;

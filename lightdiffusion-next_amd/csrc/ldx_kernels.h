@@ -42,11 +42,19 @@ struct GemmArgs {
     const void* R2; int ldr2; float oscale2;   // R2 != null: v = v * oscale2 + R2 after + R  (RRDB: out * 0.2 + x, RDRB.py:76)
     void* C; int ldc;              // 16-bit output or null
     float* Cf; int ldcf;           // fp32 output or null
+    // f8 = 1 (plain mode only): A and W are MX fp8 (OCP e4m3fn bytes, K % 128 == 0) with one E8M0 scale per 32 consecutive
+    // k; scales are stored K-tile-major as dwords SA[K/128][sa_ld] (byte j of dword [kt][m] = block 4*kt + j of row m)
+    int f8; const uint32_t* SA; int sa_ld; const uint32_t* SW; int sw_ld;
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
                                    // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
 };
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
 int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
+
+// MX quantisation of a 16-bit [rows][K] matrix (row stride ldx): per 32-element block, scale = 2^ceil(log2(amax / 448))
+// (E8M0, no clipping), y = e4m3fn(x / scale).  Y [rows][ldy] bytes; S as GemmArgs::SA (dwords [K/128][s_ld]).  K % 128 == 0.
+struct MxQuantArgs { const void* X; int ldx; int rows, K; void* Y; int ldy; uint32_t* S; int s_ld; };
+void launch_mx_quant(const MxQuantArgs& a, DType dt, hipStream_t s);
 
 // Skinny GEMM for tiny M (time embedding path): out[m][n] = bias[n] + sum_k act(x[m][k]) W[n][k]
 // x, out fp32; W 16-bit [N][K]; act: 0 none, 1 SiLU on the input (reference ResBlock emb_layers:
