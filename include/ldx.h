@@ -192,6 +192,12 @@ int ldx_tile_finish(float* out, const float* div, int64_t n, int clamp01, void* 
  * threshold <= 0 disables (default).  Stats count forwards that used / refreshed the cache. */
 int ldx_flux_fbcache(ldx_engine* e, float residual_diff_threshold);
 int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses);
+/* MX fp8 mode (BASELINE config 4 "fp8 MFMA"; opt-in, approximate, own parity class): the linears of the double / single
+ * blocks run the block-scaled 16x16x128 MFMA on e4m3fn operands with one E8M0 scale per 32 consecutive k (weights
+ * quantised once in ldx_finalize, activations per forward); everything else stays 16-bit.  Call before ldx_finalize;
+ * needs hidden_size % 128 == 0 and mlp_hidden % 128 == 0.  The reference runs Flux from Q8_0 weights (also 32-element
+ * blocks, src/Quantize/Quantizer.py:94-112) dequantised to 16-bit, i.e. W8A16; this mode is W8A8. */
+int ldx_flux_set_fp8(ldx_engine* e, int enable);
 
 /* ---- T5-XXL text encoder (Flux conditioning) ---------------------------------------------------- */
 /* Keys: T5's state dict ("shared.weight", "encoder.block.0.layer.0.SelfAttention.q.weight", ...,

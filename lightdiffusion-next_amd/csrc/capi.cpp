@@ -144,6 +144,14 @@ int ldx_flux_fbcache(ldx_engine* e, float residual_diff_threshold) {
     return LDX_OK;
     GUARD_END
 }
+int ldx_flux_set_fp8(ldx_engine* e, int enable) {
+    GUARD_BEGIN
+    if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_set_fp8: not a Flux engine"); return LDX_EINVAL; }
+    if (e->impl->finalized) { set_error("ldx_flux_set_fp8: call before ldx_finalize (the weights are quantised there)"); return LDX_ESTATE; }
+    e->impl->fx_fp8 = enable != 0;
+    return LDX_OK;
+    GUARD_END
+}
 int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses) {
     GUARD_BEGIN
     if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_fbcache_stats: not a Flux engine"); return LDX_EINVAL; }

@@ -748,6 +748,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
             case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
             case OP_GEMM: launch_gemm(o.g, dt, ls); break;
+            case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
             case OP_ATTN:
@@ -792,6 +793,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
                 else if (o.kind == OP_ATTN) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D%d", o.at.B, o.at.H, o.at.Nq, o.at.Mk, o.at.D);
                 else if (o.kind == OP_GN) snprintf(sh, sizeof(sh), " B%d HW%d C%d", o.gn.B, o.gn.HW, o.gn.C);
                 else if (o.kind == OP_LN) snprintf(sh, sizeof(sh), " R%d C%d", o.ln.rows, o.ln.C);
+                else if (o.kind == OP_MXQ) snprintf(sh, sizeof(sh), " R%d K%d", o.mq.rows, o.mq.K);
                 key += sh;
             }
             ProfEntry& pe = prof[key];

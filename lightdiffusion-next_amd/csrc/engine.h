@@ -24,7 +24,8 @@ struct HostTensor {
     float at(size_t i) const;
 };
 
-struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0; };
+struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0;
+                 void* w8 = nullptr; uint32_t* sw = nullptr; };     // MX fp8 copy + E8M0 scales [K/128][N] (Flux fp8 mode)
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0;
               float eps = 1e-5f; bool has_emb = true; };
@@ -38,11 +39,11 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
-              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G };
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
-    GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp;
+    GemmArgs g; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq;
     void* cvt_out; size_t cvt_n;
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;
@@ -87,6 +88,9 @@ public:
     void* fb_x = nullptr; int fb_B = 0, fb_L = 0, fb_Lt = 0, fb_C = 0;
     long fb_hits = 0, fb_misses = 0;
     void fb_reset() { fb_have_first = fb_have_res = false; fb_prev_valid = false; }
+    // MX fp8 mode (BASELINE config 4 "fp8 MFMA"): the block linears run on block-scaled fp8 operands; opt-in, own parity class
+    bool fx_fp8 = false;
+    bool mx_quantize_weight(LinearW& w);
     int plan_flux(int B, int h, int w, int Lt);
     int run_flux(const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,
                  const float* pe_cos, const float* pe_sin, int B, int h, int w, int Lt, bool denoise, float* out, hipStream_t st);

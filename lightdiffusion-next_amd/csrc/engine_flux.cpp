@@ -112,8 +112,31 @@ int Engine::finalize_flux() {
     }
     fx_mod_srcs.clear();
     host.clear();
+    if (fx_fp8) {
+        // MX copies of the block linears (the 16-bit copies stay: the tiny-M / ragged-K layers and the bf16 mode use them)
+        if (C % 128 || f.mlp_hidden % 128) return bad("fp8 mode needs hidden_size and mlp_hidden to be multiples of 128");
+        bool q = true;
+        for (FluxDoubleW& d : fx_double)
+            for (FluxStreamW* s : {&d.img, &d.txt}) q = q && mx_quantize_weight(s->qkv) && mx_quantize_weight(s->proj) && mx_quantize_weight(s->mlp0) && mx_quantize_weight(s->mlp2);
+        for (FluxSingleW& s : fx_single) q = q && mx_quantize_weight(s.lin1_qkv) && mx_quantize_weight(s.lin1_mlp) && mx_quantize_weight(s.lin2);
+        if (!q || hipDeviceSynchronize() != hipSuccess) { set_error(std::string("MX weight quantisation failed: ") + hipGetErrorString(hipGetLastError())); return LDX_EHIP; }
+    }
     finalized = true;
     return LDX_OK;
+}
+
+// W [N][K] 16-bit -> e4m3fn bytes [N][K] + E8M0 scales [K/128][N] (one per 32 consecutive k), on the device
+bool Engine::mx_quantize_weight(LinearW& w) {
+    void* w8 = nullptr; void* sw = nullptr;
+    if (hipMalloc(&w8, (size_t)w.N * w.K) != hipSuccess) return false;
+    dev_allocs.push_back(w8);
+    if (hipMalloc(&sw, (size_t)(w.K / 128) * w.N * 4) != hipSuccess) return false;
+    dev_allocs.push_back(sw);
+    weight_bytes += (size_t)w.N * w.K + (size_t)(w.K / 128) * w.N * 4;
+    MxQuantArgs a{w.w, w.K, w.N, w.K, w8, w.K, (uint32_t*)sw, w.N};
+    launch_mx_quant(a, dt, nullptr);
+    w.w8 = w8; w.sw = (uint32_t*)sw;
+    return hipGetLastError() == hipSuccess;
 }
 
 int Engine::plan_flux(int B, int h, int w, int Lt) {
@@ -168,7 +191,6 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         }
         release(ptok); release(ctx16);
 
-        auto mod = [&](int off, int which) { return fx_mod + off + (size_t)which * C; };   // which: 0 shift 1 scale 2 gate (+3 for mod2)
         auto ln_mod = [&](const char* name, Act Xin, Act Y, const float* shift, const float* scale, int rpb) {
             Op o{}; o.kind = OP_LN; o.name = name;
             LayerNormArgs& l = o.ln;
@@ -183,11 +205,35 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             o.i0 = tok0;                                 // first token index of this slice in the pe tables
             ops.push_back(o);
         };
-        auto gemm_gate = [&](const char* name, Act A, const LinearW& lw, Act Cc, Act R, const float* gate, int rpb, int act) {
-            op_gemm(name, A, lw, Cc, R);
+        // MX fp8 mode: an activation that feeds block linears gets an e4m3 shadow [B*L][K] + E8M0 scales [K/128][B*L], filled by
+        // a quantise op in front of its consumers; the consumers then run the block-scaled MFMA GEMM on (shadow, MX weight).
+        struct Q8 { char* y = nullptr; uint32_t* s = nullptr; int K = 0; };
+        const int RT = B * L;                                   // rows of every joint buffer = scale-array row stride
+        auto new_q8 = [&](int K) { Q8 q; q.K = K; const size_t o8 = a_alloc((size_t)RT * K), os = a_alloc((size_t)(K / 128) * RT * 4);
+                                   q.y = (char*)arena + o8; q.s = (uint32_t*)((char*)arena + os); return q; };
+        auto row_of = [&](const Act& base, const Act& v) { return (int)((v.off - base.off) / ((size_t)base.ld * 2)); };
+        auto quant = [&](const char* name, const Act& base, const Act& v, const Q8& q) {      // v: a row slice of base, all K columns
+            Op o{}; o.kind = OP_MXQ; o.name = name;
+            const int r0 = row_of(base, v);
+            o.mq = MxQuantArgs{ptr(v), v.ld, v.rows, q.K, q.y + (size_t)r0 * q.K, q.K, q.s + r0, RT};
+            o.bytes = 3.0 * (double)v.rows * q.K; snprintf(o.klabel, sizeof(o.klabel), "mx_quant_kernel");
+            ops.push_back(o);
+        };
+        // linear on the rows of `v` (a row slice of `base`): 16-bit path, or MX path reading base's shadow q
+        auto lin = [&](const char* name, const Act& base, const Act& v, const Q8& q, const LinearW& lw, Act Cc, Act R, const float* gate, int rpb, int act) {
+            op_gemm(name, v, lw, Cc, R);
             GemmArgs& g = ops.back().g;
             g.gate = gate; g.gate_ld = fx_mod_total; g.rows_per_batch = rpb; g.act = act;
             if (gate && g.splitk > 1) g.splitk = 1;      // gate/act are not replicated in the split-K reduce path for safety
+            if (fx_fp8 && lw.w8) {
+                const int r0 = row_of(base, v);
+                g.f8 = 1; g.A = q.y + (size_t)r0 * q.K; g.lda = q.K; g.SA = q.s + r0; g.sa_ld = RT; g.W = lw.w8; g.SW = lw.sw; g.sw_ld = lw.N;
+                if (!gate) {
+                    g.splitk = gemm_choose_splitk(g.M, g.N, g.K / 2, false);
+                    if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
+                }
+                snprintf(ops.back().klabel, sizeof(ops.back().klabel), "gemm_kernel<mxfp8,0>");
+            }
         };
         auto attn = [&](const char* name, Act QKV, Act O) {
             const char* base = (const char*)ptr(QKV);
@@ -196,6 +242,8 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
 
         // ---- double-stream blocks ----
         Act QKV = new_act(B * L, 3 * C), AO = new_act(B * L, C), N1 = new_act(B * L, C), MLP = new_act(B * L, MH);
+        Q8 qN1, qAO, qMLP, qCAT;
+        if (fx_fp8) { qN1 = new_q8(C); qAO = new_q8(C); qMLP = new_q8(MH); qCAT = new_q8(C + MH); }
         fb_x = ptr(X); fb_B = B; fb_L = L; fb_Lt = Lt; fb_C = C;
         int blk_i = 0;
         for (const FluxDoubleW& blk : fx_double) {
@@ -209,16 +257,20 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total;
                     ln_mod("fx.d.norm1", s.x, s.n, m + s.w->mod_off + 0 * C, m + s.w->mod_off + 1 * C, s.rows);
-                    op_gemm("fx.d.qkv", s.n, s.w->qkv, s.qkv, Act{});
+                    if (fx_fp8) quant("fx.d.q.norm1", N1, s.n, qN1);
+                    lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
                     rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
                 }
                 attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L));          // joint [txt ; img] sequence
+                if (fx_fp8) quant("fx.d.q.attn", AO, rows(AO, b * L, L), qAO);
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
-                    gemm_gate("fx.d.proj", s.ao, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);          // x += gate1 * proj(attn)
+                    lin("fx.d.proj", AO, s.ao, qAO, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);        // x += gate1 * proj(attn)
                     ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows);
-                    gemm_gate("fx.d.mlp0", s.n, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2);         // tanh-GELU
-                    gemm_gate("fx.d.mlp2", s.mlp, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);         // x += gate2 * mlp(...)
+                    if (fx_fp8) quant("fx.d.q.norm2", N1, s.n, qN1);
+                    lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2);       // tanh-GELU
+                    if (fx_fp8) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
+                    lin("fx.d.mlp2", MLP, s.mlp, qMLP, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);     // x += gate2 * mlp(...)
                 }
             }
         }
@@ -231,11 +283,13 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 const float* m = fx_mod + (size_t)b * fx_mod_total + blk.mod_off;
                 Act xb = rows(X, b * L, L), nb = rows(N1, b * L, L), qb = rows(QKV, b * L, L), cb = rows(CAT, b * L, L);
                 ln_mod("fx.s.pre_norm", xb, nb, m + 0 * C, m + 1 * C, L);
-                op_gemm("fx.s.lin1.qkv", nb, blk.lin1_qkv, qb, Act{});
-                gemm_gate("fx.s.lin1.mlp", nb, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2);
+                if (fx_fp8) quant("fx.s.q.norm", N1, nb, qN1);
+                lin("fx.s.lin1.qkv", N1, nb, qN1, blk.lin1_qkv, qb, Act{}, nullptr, L, 0);
+                lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2);
                 rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);
                 attn("fx.s.attn", qb, view(cb, 0, C));
-                gemm_gate("fx.s.lin2", cb, blk.lin2, xb, xb, m + 2 * C, L, 0);                      // x += gate * linear2(cat)
+                if (fx_fp8) quant("fx.s.q.cat", CAT, cb, qCAT);
+                lin("fx.s.lin2", CAT, cb, qCAT, blk.lin2, xb, xb, m + 2 * C, L, 0);                 // x += gate * linear2(cat)
             }
         }
         release(CAT); release(QKV); release(AO);

@@ -466,7 +466,8 @@ def flux_rope_tables(cfg: FluxConfig, batch_txt_len: int, h: int, w: int):
 class FluxEngine:
     """Flux3.forward behind BaseModel.apply_model with CONST prediction."""
 
-    def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16"):
+    def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16", fp8: bool = False):
+        """fp8=True: the block linears run on MX fp8 operands (ldx_flux_set_fp8; approximate, opt-in)."""
         self._lib = lib.load()
         self._h = C.c_void_p()
         self.cfg, self.device = cfg, torch.device("cuda", device)
@@ -476,6 +477,8 @@ class FluxEngine:
         c.hidden_size, c.mlp_hidden, c.num_heads = cfg.hidden_size, cfg.mlp_hidden, cfg.num_heads
         c.depth, c.depth_single, c.guidance_embed = cfg.depth, cfg.depth_single_blocks, int(cfg.guidance_embed)
         lib.check(self._lib.ldx_flux_create(C.byref(c), device, C.byref(self._h)), "ldx_flux_create")
+        if fp8:
+            lib.check(self._lib.ldx_flux_set_fp8(self._h, 1), "ldx_flux_set_fp8")
         _load_state_dict(self._lib, self._h, state_dict, strip=("model.diffusion_model.",))
         lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
         self._pe = {}

@@ -15,6 +15,8 @@ and running plain fp32 ops is bit-identical to that path (probed
 """
 import math
 
+import numpy as np
+
 import torch
 import torch.nn.functional as F
 
@@ -792,11 +794,39 @@ class FluxFBCache:
         return float((self.first - r).abs().mean() / self.first.abs().mean()) < self.threshold
 
 
-def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None):
+def mx_fake_quant(t):
+    """OCP microscaling fp8 along the last axis (a multiple of 32), returned DEQUANTISED in fp32: per block of 32 consecutive
+    elements, scale = 2^ceil(log2(amax / 448)) (E8M0, exponent clamped to [-126, 126]), element = e4m3fn(x / scale) rounded
+    to nearest even.  This is the build's MX fp8 mode (include/ldx.h: ldx_op_mx_quant / ldx_flux_set_fp8); the reference has
+    no fp8 path (its Flux runs from Q8_0 weights dequantised to 16-bit, Quantizer.py:94-112), so this mode is NOT pinned by
+    the reference: it is pinned by this rule, bit-for-bit at the op level (tests/test_mx_gpu.py)."""
+    shp = t.shape
+    xb = t.float().reshape(-1, shp[-1] // 32, 32)
+    amax = xb.abs().amax(-1)
+    r = amax * torch.tensor(np.float32(1.0) / np.float32(448.0))
+    bits = r.view(torch.int32)
+    e = (((bits >> 23) & 0xFF) + ((bits & 0x7FFFFF) != 0).to(torch.int32)).clamp(1, 253)
+    inv = ((254 - e) << 23).view(torch.float32)
+    scale = (e << 23).view(torch.float32)
+    q = (xb * inv[..., None]).to(torch.float8_e4m3fn).float()
+    return (q * scale[..., None]).reshape(shp)
+
+
+_MX_LINEARS = ("_attn.qkv", "_attn.proj", "_mlp.0", "_mlp.2", ".linear1", ".linear2")
+
+
+def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False):
     """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output.
-    fb: optional FluxFBCache (approximate mode)."""
+    fb: optional FluxFBCache (approximate mode).  mx: the build's MX fp8 mode — input and weight of every double / single
+    block linear pass through mx_fake_quant (fp32 accumulation, everything else unchanged)."""
     w = W(sd)
-    lin = lambda name, t: F.linear(t, w(name + ".weight"), w(name + ".bias") if w.has(name + ".bias") else None)
+
+    def lin(name, t):
+        wt = w(name + ".weight")
+        if mx and name.endswith(_MX_LINEARS):
+            t, wt = mx_fake_quant(t), mx_fake_quant(wt)
+        return F.linear(t, wt, w(name + ".bias") if w.has(name + ".bias") else None)
+
     mlp_emb = lambda name, t: lin(name + ".out_layer", F.silu(lin(name + ".in_layer", t)))
     bs, c, h, wd = x.shape
     hl, wl = h // 2, wd // 2

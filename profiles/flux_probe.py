@@ -22,7 +22,9 @@ for k, shp in spec:        # cheap fill: one small random block tiled (values do
         sd[k] = base.repeat((n + base.numel() - 1) // base.numel())[:n].reshape(shp).half()
 print(f"weights: {ldx.weights.param_count(spec)/1e9:.2f} B params generated in {time.time()-t0:.1f} s", flush=True)
 t0 = time.time()
-eng = ldx.FluxEngine(cfg, sd, dtype="bf16")
+FP8 = os.environ.get("LDX_FLUX_FP8", "0") == "1"
+eng = ldx.FluxEngine(cfg, sd, dtype="bf16", fp8=FP8)
+print("fp8 (MX) mode:", FP8)
 del sd
 print(f"engine built in {time.time()-t0:.1f} s", flush=True)
 x = torch.randn(1, 16, 128, 128, device="cuda"); ctx = torch.randn(1, 256, 4096, device="cuda"); y = torch.randn(1, 768, device="cuda")
