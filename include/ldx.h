@@ -249,10 +249,18 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
  * 2^ceil(log2(amax/448)), elements are e4m3fn = x / scale rounded to nearest even; BASELINE config 4 "fp8 MFMA").
  * ldx_op_mx_quant: 16-bit X [rows][K] (stride ldx) -> Y bytes [rows][ldy] + scales: uint32 [K/128][scales_ld], byte j of
  * word [t][r] = scale of block 4 t + j of row r.  ldx_op_gemm_mx: C = act(A W^T + bias) (+ R) on such operands (A [M][K],
- * W [N][K]); fp32 accumulation; act as ldx_kernels.h GemmArgs::act; outputs 16-bit C and / or fp32 Cf. */
+ * W [N][K]); fp32 accumulation; act as ldx_kernels.h GemmArgs::act; outputs 16-bit C and / or fp32 Cf — or, with C8 / SC
+ * (N % 128 == 0, no R / C / Cf), the result quantised in the epilogue exactly as ldx_op_mx_quant would quantise the 16-bit
+ * C: the operand of the next block-scaled GEMM without a separate pass. */
+/* Attention (head dim 128, no mask) whose output is quantised in the epilogue exactly as ldx_op_mx_quant would quantise the
+ * 16-bit O [B*Nq][H*128]: O8 bytes (row stride ldo8) + scales uint32 [H][so_ld] (one word per row and head).  Needs
+ * B * H * ceil(Nq / 128) >= 64 workgroups (smaller problems: ldx_op_attention + ldx_op_mx_quant). */
+int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O8, int ldo8, void* SO, int so_ld,
+                        int B, int H, int Nq, int Mk, float scale, int dtype, void* stream);
 int ldx_op_mx_quant(const void* X, int ldx, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream);
 int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const void* W8, const void* SW, int sw_ld, int M, int N, int K,
-                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream);
+                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf,
+                   void* C8, int ldc8, void* SC, int sc_ld, int dtype, void* stream);
 int ldx_op_conv3x3(const void* X, int ldx, const void* W, int B, int Hin, int Win, int Cin, int Cout,
                    int stride, int Hout, int Wout, int resize_to_out, const float* bias,
                    const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,

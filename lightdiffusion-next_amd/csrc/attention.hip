@@ -751,6 +751,31 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
         const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
         const float inv = (l > 0.f) ? 1.0f / l : 0.f;
         const int q = q0 + qt * 32 + l31;
+        if constexpr (NDT == 4 && !ONES) {
+            // MX fp8 output (D = 128: the 4 tiles dt are the head's 4 blocks of 32; a block is split over the two half-waves)
+            if (p.O8) {
+                uint32_t sc = 0;
+                char* o8 = (char*)p.O8 + ((long)b * p.Nq + q) * p.ldo8 + h * 128;
+#pragma unroll
+                for (int dt = 0; dt < 4; ++dt) {
+                    float v[16], amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { v[r] = to_f32(from_f32<T>(o[qt][dt][r] * inv)); amax = fmaxf(amax, fabsf(v[r])); }
+                    auto am = __builtin_amdgcn_permlane32_swap(__float_as_uint(amax), __float_as_uint(amax), false, false);
+                    amax = fmaxf(__uint_as_float(am[0]), __uint_as_float(am[1]));
+                    const int e = mx_scale_e8m0(amax);
+                    const float is = mx_inv_scale(e);
+                    sc |= (uint32_t)e << (8 * dt);
+                    if (q < p.Nq) {
+#pragma unroll
+                        for (int rq = 0; rq < 4; ++rq)
+                            *(uint32_t*)(o8 + dt * 32 + 8 * rq + 4 * h2) = mx_pack4(v[4 * rq] * is, v[4 * rq + 1] * is, v[4 * rq + 2] * is, v[4 * rq + 3] * is);
+                    }
+                }
+                if (q < p.Nq && h2 == 0) p.SO[(long)h * p.so_ld + (long)b * p.Nq + q] = sc;
+                continue;
+            }
+        }
         if (q >= p.Nq) continue;
 #pragma unroll
         for (int dt = 0; dt < NDT; ++dt)
@@ -776,18 +801,28 @@ static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
 // head dims served by the generic 32x32x16 kernel (LDX_ATTN32G bit mask 1: D=80, 2: D=160, 4: D=128, 8: D=64).  Default 7: same-box
 // step A/B 54.76 -> 55.34 it/s with D = 80 and 160; D = 128 (Flux, VALU denominator instead of a fifth d tile) 19.6 -> 18.4 ms of
 // attention per forward; D = 64 only appears with a causal mask or a bias on this path.
-template <typename T>
-static bool try_attn32g(const AttnArgs& a, hipStream_t s) {
+static int attn32g_variant(const AttnArgs& a) {      // 0: not taken, else the head dim handled by a 32x32 instantiation
     static const int mask = getenv("LDX_ATTN32G") ? atoi(getenv("LDX_ATTN32G")) : 7;
-    if (!mask || a.causal || a.bias) return false;
+    if (!mask || a.causal || a.bias) return 0;
     const long wg = (long)((a.Nq + 127) / 128) * a.H * a.B;
     static const long min_wg = getenv("LDX_ATTN32G_MINWG") ? atol(getenv("LDX_ATTN32G_MINWG")) : 64;
-    if (wg < min_wg) return false;
-    if ((mask & 1) && a.D == 80) { launch_attn32g<T, 5, 3, 1, true>(a, s); return true; }
-    if ((mask & 2) && a.D == 160) { launch_attn32g<T, 10, 6, 1, true>(a, s); return true; }
-    if ((mask & 4) && a.D == 128) { launch_attn32g<T, 8, 4, 1, false>(a, s); return true; }
-    if ((mask & 8) && a.D == 64) { launch_attn32g<T, 4, 2, 1, false>(a, s); return true; }
-    return false;
+    if (wg < min_wg) return 0;
+    if ((mask & 1) && a.D == 80) return 80;
+    if ((mask & 2) && a.D == 160) return 160;
+    if ((mask & 4) && a.D == 128) return 128;
+    if ((mask & 8) && a.D == 64) return 64;
+    return 0;
+}
+bool attention_mx_out_ok(const AttnArgs& a) { return attn32g_variant(a) == 128; }
+template <typename T>
+static bool try_attn32g(const AttnArgs& a, hipStream_t s) {
+    switch (attn32g_variant(a)) {
+        case 80: launch_attn32g<T, 5, 3, 1, true>(a, s); return true;
+        case 160: launch_attn32g<T, 10, 6, 1, true>(a, s); return true;
+        case 128: launch_attn32g<T, 8, 4, 1, false>(a, s); return true;
+        case 64: launch_attn32g<T, 4, 2, 1, false>(a, s); return true;
+        default: return false;
+    }
 }
 
 template <typename T, int KS, int DT, int QT>

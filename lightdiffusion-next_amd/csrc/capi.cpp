@@ -282,6 +282,17 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm");
 }
+int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O8, int ldo8, void* SO, int so_ld,
+                        int B, int H, int Nq, int Mk, float scale, int dtype, void* stream) {
+    AttnArgs a{};
+    a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.B = B; a.H = H; a.Nq = Nq; a.Mk = Mk; a.D = 128; a.scale = scale;
+    a.O8 = O8; a.ldo8 = ldo8; a.SO = (uint32_t*)SO; a.so_ld = so_ld;
+    if (!Q || !K || !V || !O8 || !SO || B <= 0 || H <= 0 || Nq <= 0 || Mk <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo8 % 16 || ldo8 < H * 128 || so_ld < B * Nq) {
+        set_error("ldx_op_attention_mx: bad argument"); return LDX_EINVAL; }
+    if (!attention_mx_out_ok(a)) { set_error("ldx_op_attention_mx: needs head dim 128 and at least 64 query blocks of 128 (B * H * ceil(Nq / 128))"); return LDX_EINVAL; }
+    launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_attention_mx");
+}
 int ldx_op_mx_quant(const void* X, int ldx_, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream) {
     if (!X || !Y || !scales || rows <= 0 || K <= 0 || K % 128 || ldx_ % 8 || ldy % 16 || ldy < K || scales_ld < rows) {
         set_error("ldx_op_mx_quant: bad argument (K % 128, ldx % 8, ldy % 16, scales_ld >= rows)"); return LDX_EINVAL; }
@@ -290,14 +301,18 @@ int ldx_op_mx_quant(const void* X, int ldx_, int rows, int K, void* Y, int ldy, 
     return check_launch("ldx_op_mx_quant");
 }
 int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const void* W8, const void* SW, int sw_ld, int M, int N, int K,
-                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf, int dtype, void* stream) {
-    if (!A8 || !W8 || !SA || !SW || M <= 0 || N <= 0 || K <= 0 || K % 128 || lda % 16 || sa_ld < M || sw_ld < N || (!C && !Cf) || act < 0 || act > 3) {
+                   const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf,
+                   void* C8, int ldc8, void* SC, int sc_ld, int dtype, void* stream) {
+    if (!A8 || !W8 || !SA || !SW || M <= 0 || N <= 0 || K <= 0 || K % 128 || lda % 16 || sa_ld < M || sw_ld < N || (!C && !Cf && !C8) || act < 0 || act > 3) {
         set_error("ldx_op_gemm_mx: bad argument (K % 128, lda % 16, sa_ld >= M, sw_ld >= N)"); return LDX_EINVAL; }
+    if (C8 && (!SC || N % 128 || ldc8 % 16 || ldc8 < N || sc_ld < M || R || C || Cf)) {
+        set_error("ldx_op_gemm_mx: MX output needs N % 128 == 0, ldc8 % 16 == 0, scales_ld >= M and no other output / residual"); return LDX_EINVAL; }
     GemmArgs g{};
     g.A = A8; g.lda = lda; g.W = W8; g.M = M; g.N = N; g.K = K; g.mode = 0; g.bias = bias; g.rows_per_batch = 1; g.act = act;
     g.f8 = 1; g.SA = (const uint32_t*)SA; g.sa_ld = sa_ld; g.SW = (const uint32_t*)SW; g.sw_ld = sw_ld;
     g.R = R; g.ldr = ldr; g.C = C; g.ldc = ldc; g.Cf = Cf; g.ldcf = ldcf;
-    g.splitk = gemm_choose_splitk(M, N, K / 2, false);
+    g.C8 = C8; g.ldc8 = ldc8; g.c8_col = 0; g.SC = (uint32_t*)SC; g.sc_ld = sc_ld;
+    g.splitk = C8 ? 1 : gemm_choose_splitk(M, N, K / 2, false);
     if (g.splitk > 1) {
         g.ws = op_workspace((size_t)g.splitk * M * N);
         if (!g.ws) { set_error("split-K workspace allocation failed"); return LDX_EHIP; }

@@ -11,6 +11,7 @@
 // adaLN modulation projections are one batched skinny GEMM on SiLU(vec) per forward.
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 #include "engine.h"
@@ -208,19 +209,24 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         // MX fp8 mode: an activation that feeds block linears gets an e4m3 shadow [B*L][K] + E8M0 scales [K/128][B*L], filled by
         // a quantise op in front of its consumers; the consumers then run the block-scaled MFMA GEMM on (shadow, MX weight).
         struct Q8 { char* y = nullptr; uint32_t* s = nullptr; int K = 0; };
+        static const int fuse_mask = getenv("LDX_MX_FUSE") ? atoi(getenv("LDX_MX_FUSE")) : 7;      // experiment switch: 1 GEMM epilogue, 2 attention, 4 LayerNorm
+        const bool fuse_gemm_q = fuse_mask & 1;
         const int RT = B * L;                                   // rows of every joint buffer = scale-array row stride
         auto new_q8 = [&](int K) { Q8 q; q.K = K; const size_t o8 = a_alloc((size_t)RT * K), os = a_alloc((size_t)(K / 128) * RT * 4);
                                    q.y = (char*)arena + o8; q.s = (uint32_t*)((char*)arena + os); return q; };
         auto row_of = [&](const Act& base, const Act& v) { return (int)((v.off - base.off) / ((size_t)base.ld * 2)); };
-        auto quant = [&](const char* name, const Act& base, const Act& v, const Q8& q) {      // v: a row slice of base, all K columns
+        auto quant = [&](const char* name, const Act& base, const Act& v, const Q8& q, int ncols = 0) {      // v: a row slice of base; its first ncols columns (0 = all)
             Op o{}; o.kind = OP_MXQ; o.name = name;
-            const int r0 = row_of(base, v);
-            o.mq = MxQuantArgs{ptr(v), v.ld, v.rows, q.K, q.y + (size_t)r0 * q.K, q.K, q.s + r0, RT};
-            o.bytes = 3.0 * (double)v.rows * q.K; snprintf(o.klabel, sizeof(o.klabel), "mx_quant_kernel");
+            const int r0 = row_of(base, v), K = ncols ? ncols : q.K;
+            o.mq = MxQuantArgs{ptr(v), v.ld, v.rows, K, q.y + (size_t)r0 * q.K, q.K, q.s + r0, RT};
+            o.bytes = 3.0 * (double)v.rows * K; snprintf(o.klabel, sizeof(o.klabel), "mx_quant_kernel");
             ops.push_back(o);
         };
         // linear on the rows of `v` (a row slice of `base`): 16-bit path, or MX path reading base's shadow q
-        auto lin = [&](const char* name, const Act& base, const Act& v, const Q8& q, const LinearW& lw, Act Cc, Act R, const float* gate, int rpb, int act) {
+        // qo != null (MX mode, no gate / residual): the output goes straight to the shadow qo of the buffer Cc lives in, at
+        // Cc's rows and columns, quantised in the GEMM epilogue (Cc itself is not written)
+        auto lin = [&](const char* name, const Act& base, const Act& v, const Q8& q, const LinearW& lw, Act Cc, Act R, const float* gate, int rpb, int act,
+                       const Q8* qo = nullptr, const Act* obase = nullptr) {
             op_gemm(name, v, lw, Cc, R);
             GemmArgs& g = ops.back().g;
             g.gate = gate; g.gate_ld = fx_mod_total; g.rows_per_batch = rpb; g.act = act;
@@ -233,11 +239,21 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                     if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
                 }
                 snprintf(ops.back().klabel, sizeof(ops.back().klabel), "gemm_kernel<mxfp8,0>");
+                if (qo && fuse_gemm_q) {
+                    const int ro = (int)((Cc.off - obase->off) / ((size_t)obase->ld * 2));
+                    g.C = nullptr; g.C8 = qo->y + (size_t)ro * qo->K; g.ldc8 = qo->K; g.c8_col = Cc.col - obase->col; g.SC = qo->s + ro; g.sc_ld = RT; g.splitk = 1;
+                }
             }
         };
-        auto attn = [&](const char* name, Act QKV, Act O) {
+        // returns true if the attention kernel wrote the MX shadow qo of obase itself (head dim 128, large grid)
+        auto attn = [&](const char* name, Act QKV, Act O, const Q8* qo = nullptr, const Act* obase = nullptr) {
             const char* base = (const char*)ptr(QKV);
             op_attn(name, base, QKV.ld, base + (size_t)C * 2, QKV.ld, base + (size_t)2 * C * 2, QKV.ld, O, 1, H, QKV.rows, QKV.rows, D);
+            AttnArgs& a = ops.back().at;
+            if (!fx_fp8 || !qo || !(fuse_mask & 2) || !attention_mx_out_ok(a)) return false;
+            const int ro = row_of(*obase, O);
+            a.O8 = qo->y + (size_t)ro * qo->K; a.ldo8 = qo->K; a.SO = qo->s + ro; a.so_ld = RT;
+            return true;
         };
 
         // ---- double-stream blocks ----
@@ -261,15 +277,15 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                     lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
                     rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
                 }
-                attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L));          // joint [txt ; img] sequence
-                if (fx_fp8) quant("fx.d.q.attn", AO, rows(AO, b * L, L), qAO);
+                const bool aq = attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L), &qAO, &AO);          // joint [txt ; img] sequence
+                if (fx_fp8 && !aq) quant("fx.d.q.attn", AO, rows(AO, b * L, L), qAO);
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
                     lin("fx.d.proj", AO, s.ao, qAO, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);        // x += gate1 * proj(attn)
                     ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows);
                     if (fx_fp8) quant("fx.d.q.norm2", N1, s.n, qN1);
-                    lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2);       // tanh-GELU
-                    if (fx_fp8) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
+                    lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2, &qMLP, &MLP);       // tanh-GELU
+                    if (fx_fp8 && !fuse_gemm_q) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
                     lin("fx.d.mlp2", MLP, s.mlp, qMLP, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);     // x += gate2 * mlp(...)
                 }
             }
@@ -285,10 +301,10 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 ln_mod("fx.s.pre_norm", xb, nb, m + 0 * C, m + 1 * C, L);
                 if (fx_fp8) quant("fx.s.q.norm", N1, nb, qN1);
                 lin("fx.s.lin1.qkv", N1, nb, qN1, blk.lin1_qkv, qb, Act{}, nullptr, L, 0);
-                lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2);
+                lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2, &qCAT, &CAT);
                 rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);
-                attn("fx.s.attn", qb, view(cb, 0, C));
-                if (fx_fp8) quant("fx.s.q.cat", CAT, cb, qCAT);
+                const bool aq = attn("fx.s.attn", qb, view(cb, 0, C), &qCAT, &CAT);
+                if (fx_fp8 && !(aq && fuse_gemm_q)) quant("fx.s.q.cat", CAT, cb, qCAT, fuse_gemm_q ? C : 0);
                 lin("fx.s.lin2", CAT, cb, qCAT, blk.lin2, xb, xb, m + 2 * C, L, 0);                 // x += gate * linear2(cat)
             }
         }

@@ -274,6 +274,48 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
         }
         return;
     }
+    // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
+    if (p.C8) {
+        if constexpr ((BN / 2) % 32 == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+                const bool live = m < p.M;                      // no early exit: every lane takes part in the exchanges
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    const int n = n0 + wn * (BN / 2) + jp * 32 + 4 * g4;
+                    const bool nok = n < p.N;                   // N % 32 == 0: a block is inside or outside as a whole
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                    if (p.bias && nok) {
+                        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 16);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (p.act == 1) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                        else if (p.act == 2) v[r] = gelu_tanh_f(v[r]);
+                        else if (p.act == 3) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                        v[r] = to_f32(from_f32<T>(v[r]));       // the value the 16-bit path would have stored (same input to the quantiser)
+                        amax = fmaxf(amax, fabsf(v[r]));
+                    }
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    const int e = mx_scale_e8m0(amax);
+                    const float inv = mx_inv_scale(e);
+                    if (live && nok) {
+                        char* dst = (char*)p.C8 + (long)m * p.ldc8 + p.c8_col + n;
+                        *(uint32_t*)dst = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+                        *(uint32_t*)(dst + 16) = mx_pack4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+                        if (g4 == 0) { const int kb = (p.c8_col + n) >> 5; ((uint8_t*)p.SC)[((long)(kb >> 2) * p.sc_ld + m) * 4 + (kb & 3)] = (uint8_t)e; }
+                    }
+                }
+            }
+        }
+        return;
+    }
     // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
     const T* __restrict__ Rp = (const T*)p.R;
     T* __restrict__ Cp = (T*)p.C;
@@ -445,7 +487,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
         const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S);
         if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
-        else if (t.bn == 160) launch_gemm_inst<T, 0, 128, 160, 2, true>(a, S, s);
+        else if (t.bn == 160 && !a.C8) launch_gemm_inst<T, 0, 128, 160, 2, true>(a, S, s);
         else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
         return;
     }

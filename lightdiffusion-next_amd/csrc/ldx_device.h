@@ -44,6 +44,20 @@ __device__ __forceinline__ f32x4 mfma16_mx(i32x8 a, i32x8 b, f32x4 c, int sa, in
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, sa, 0, sb);
 }
 
+// MX quantisation rule shared by every producer of MX operands (mx.hip header): E8M0 exponent for a block with the given
+// amax, the matching inverse scale, and four fp32 -> four e4m3fn bytes (round to nearest even), packed little-endian.
+__device__ __forceinline__ int mx_scale_e8m0(float amax) {
+    const uint32_t b = __float_as_uint(amax * (1.0f / 448.0f));
+    int e = (int)((b >> 23) & 0xff) + ((b & 0x7fffff) ? 1 : 0);
+    return min(max(e, 1), 253);
+}
+__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((uint32_t)(254 - e) << 23); }
+__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d) {
+    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
+    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
+    return (uint32_t)v;
+}
+
 union U128 {
     uint4 u;
     bf16x8 b;

@@ -45,6 +45,10 @@ struct GemmArgs {
     // f8 = 1 (plain mode only): A and W are MX fp8 (OCP e4m3fn bytes, K % 128 == 0) with one E8M0 scale per 32 consecutive
     // k; scales are stored K-tile-major as dwords SA[K/128][sa_ld] (byte j of dword [kt][m] = block 4*kt + j of row m)
     int f8; const uint32_t* SA; int sa_ld; const uint32_t* SW; int sw_ld;
+    // C8 != null: the output is written as MX fp8 instead of 16-bit C (bias and act only; N % 32 == 0, tile width 64 or 128):
+    // bytes C8[m][c8_col + n], scales SC (SA layout, row stride sc_ld) for the blocks (c8_col + n) / 32 — the operand of the
+    // next block-scaled GEMM, produced without a separate quantisation pass
+    void* C8; int ldc8; int c8_col; uint32_t* SC; int sc_ld;
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
                                    // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
 };
@@ -77,8 +81,12 @@ struct AttnArgs {
     // optional additive score bias (T5 relative-position bias): fp32 [H][>= Nq][bias_ld], bias_ld = Mk rounded up to 64,
     // shared by the batch, added to q.k BEFORE the scale (pass bias / scale); padded entries are ignored
     const float* bias; int bias_ld; long bias_hs;
+    // O8 != null (only when attention_mx_out_ok(a)): the output is written as MX fp8 instead of 16-bit O — bytes
+    // O8[b*Nq + n][h*D + d] (row stride ldo8) and, D being 128, one scale dword per (row, head): SO[h][b*Nq + n] (row stride so_ld)
+    void* O8; int ldo8; uint32_t* SO; int so_ld;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+bool attention_mx_out_ok(const AttnArgs& a);      // true if launch_attention will take a kernel that implements O8 / SO
 
 // ---------------------------------------------------------------------------------------------
 // GroupNorm(32 groups) over NHWC + optional SiLU.  Two launches: partial statistics, then apply.

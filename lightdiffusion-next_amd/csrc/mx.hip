@@ -11,19 +11,6 @@
 
 namespace ldx {
 
-__device__ __forceinline__ int mx_scale_e8m0(float amax) {
-    const uint32_t b = __float_as_uint(amax * (1.0f / 448.0f));
-    int e = (int)((b >> 23) & 0xff) + ((b & 0x7fffff) ? 1 : 0);
-    return min(max(e, 1), 253);
-}
-__device__ __forceinline__ float mx_inv_scale(int e) { return __uint_as_float((uint32_t)(254 - e) << 23); }
-// four fp32 -> four e4m3fn bytes (round to nearest even), packed little-endian
-__device__ __forceinline__ uint32_t mx_pack4(float a, float b, float c, float d) {
-    int v = __builtin_amdgcn_cvt_pk_fp8_f32(a, b, 0, false);
-    v = __builtin_amdgcn_cvt_pk_fp8_f32(c, d, v, true);
-    return (uint32_t)v;
-}
-
 // one thread per 32-element block: 4 x 16-B loads, 2 x 16-B stores, one scale byte
 template <typename T>
 __global__ __launch_bounds__(256) void mx_quant_kernel(const MxQuantArgs p) {

@@ -25,7 +25,7 @@ for M, N, K in SHAPES:
     q = lambda: L.ldx_op_mx_quant(p(A), K, M, K, p(A8), K, p(SA), M, 0, st())
     assert q() == 0 and L.ldx_op_mx_quant(p(W), K, N, K, p(W8), K, p(SW), N, 0, st()) == 0
     f16 = lambda: L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, 0, None, 0, p(Cc), N, None, 0, 0, st())
-    f8 = lambda: L.ldx_op_gemm_mx(p(A8), K, p(SA), M, p(W8), p(SW), N, M, N, K, None, 0, None, 0, p(Cc), N, None, 0, 0, st())
+    f8 = lambda: L.ldx_op_gemm_mx(p(A8), K, p(SA), M, p(W8), p(SW), N, M, N, K, None, 0, None, 0, p(Cc), N, None, 0, None, 0, None, 0, 0, st())
     assert f16() == 0
     ref = Cc.float().clone()
     assert f8() == 0

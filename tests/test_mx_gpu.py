@@ -98,7 +98,7 @@ def test_gemm_mx(ldx_lib, ldx, dt, M, N, K):
     Cf = torch.zeros(M, N, device="cuda", dtype=torch.float32)
     Rg = R.cuda()
     ldx.lib.check(L.ldx_op_gemm_mx(_p(A8), K, _p(SA), M + 3, _p(W8), _p(SW), N, M, N, K, _p(bias.cuda()), 2, _p(Rg), N + 8,
-                                   _p(Cc), N + 8, _p(Cf), N, code, _st()), "gemm_mx")
+                                   _p(Cc), N + 8, _p(Cf), N, None, 0, None, 0, code, _st()), "gemm_mx")
     torch.cuda.synchronize()
     _, _, Ad = mx_quant_ref(A.float())
     _, _, Wd = mx_quant_ref(W.float())
@@ -116,6 +116,34 @@ def test_gemm_mx(ldx_lib, ldx, dt, M, N, K):
     assert qerr < 6e-2, f"quantisation error {qerr:.3e}"
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("M,N,K", [(300, 256, 384), (1024, 1280, 3072), (4096, 1024, 256), (77, 128, 128)])
+def test_gemm_mx_quantised_output(ldx_lib, ldx, dt, M, N, K):
+    """MX output epilogue == 16-bit output followed by ldx_op_mx_quant, bit for bit (bytes and scales)."""
+    L = ldx_lib
+    td, code = DT[dt]
+    g = torch.Generator().manual_seed(M * 3 + N + K)
+    A = torch.randn(M, K, generator=g).to(td).cuda()
+    W = (torch.randn(N, K, generator=g) / math.sqrt(K) * torch.exp(torch.randn(N, 1, generator=g))).to(td).cuda()
+    bias = torch.randn(N, generator=g).cuda()
+    A8, SA = quant_gpu(L, ldx, A, K, code)
+    W8, SW = quant_gpu(L, ldx, W, K, code)
+    Cc = torch.zeros(M, N, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_gemm_mx(_p(A8), K, _p(SA), M, _p(W8), _p(SW), N, M, N, K, _p(bias), 2, None, 0, _p(Cc), N, None, 0,
+                                   None, 0, None, 0, code, _st()), "gemm_mx")
+    Y2, S2 = quant_gpu(L, ldx, Cc, N, code, ldy=N + 32, s_ld=M + 7)
+    Y1 = torch.zeros(M, N + 32, device="cuda", dtype=torch.uint8)
+    S1 = torch.zeros(N // 128, M + 7, 4, device="cuda", dtype=torch.uint8)
+    ldx.lib.check(L.ldx_op_gemm_mx(_p(A8), K, _p(SA), M, _p(W8), _p(SW), N, M, N, K, _p(bias), 2, None, 0, None, 0, None, 0,
+                                   _p(Y1), N + 32, _p(S1), M + 7, code, _st()), "gemm_mx C8")
+    torch.cuda.synchronize()
+    assert torch.equal(S1.cpu(), S2.cpu()), "scales differ"
+    a, b = Y1.cpu()[:, :N].clone(), Y2.cpu()[:, :N].clone()
+    a[(a & 0x7F) == 0] = 0
+    b[(b & 0x7F) == 0] = 0
+    assert torch.equal(a, b), f"{int((a != b).sum())} bytes differ"
+
+
 def test_mx_bad_args(ldx_lib, ldx):
     L = ldx_lib
     x = torch.zeros(4, 128, device="cuda", dtype=torch.bfloat16)
@@ -123,4 +151,36 @@ def test_mx_bad_args(ldx_lib, ldx):
     s = torch.zeros(1, 4, 4, device="cuda", dtype=torch.uint8)
     assert L.ldx_op_mx_quant(_p(x), 128, 4, 96, _p(y), 128, _p(s), 4, 0, _st()) != 0          # K % 128
     assert L.ldx_op_mx_quant(_p(x), 128, 4, 128, _p(y), 128, _p(s), 2, 0, _st()) != 0         # scales_ld < rows
-    assert L.ldx_op_gemm_mx(_p(y), 128, _p(s), 4, _p(y), _p(s), 4, 4, 4, 64, None, 0, None, 0, _p(x), 128, None, 0, 0, _st()) != 0
+    assert L.ldx_op_gemm_mx(_p(y), 128, _p(s), 4, _p(y), _p(s), 4, 4, 4, 64, None, 0, None, 0, _p(x), 128, None, 0, None, 0, None, 0, 0, _st()) != 0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,N", [(1, 24, 4352), (2, 4, 1100)])
+def test_attention_mx_output(ldx_lib, ldx, dt, B, H, N):
+    """Attention with the MX output epilogue == ldx_op_attention followed by ldx_op_mx_quant, bit for bit."""
+    L = ldx_lib
+    td, code = DT[dt]
+    D, Cn = 128, H * 128
+    g = torch.Generator().manual_seed(B + H + N)
+    qkv = torch.randn(B, N, 3 * Cn, generator=g).to(td).cuda()
+    O = torch.zeros(B * N, Cn, device="cuda", dtype=td)
+    sc = 1.0 / math.sqrt(D)
+    q, k, v = qkv[..., :Cn], qkv[..., Cn:2 * Cn], qkv[..., 2 * Cn:]
+    ldx.lib.check(L.ldx_op_attention(_p(q), 3 * Cn, _p(k), 3 * Cn, _p(v), 3 * Cn, _p(O), Cn, B, H, N, N, D, sc, 0, code, _st()), "attention")
+    Y2, S2 = quant_gpu(L, ldx, O, Cn, code, ldy=Cn + 16, s_ld=B * N + 9)
+    Y1 = torch.zeros(B * N, Cn + 16, device="cuda", dtype=torch.uint8)
+    S1 = torch.zeros(Cn // 128, B * N + 9, 4, device="cuda", dtype=torch.uint8)
+    ldx.lib.check(L.ldx_op_attention_mx(_p(q), 3 * Cn, _p(k), 3 * Cn, _p(v), 3 * Cn, _p(Y1), Cn + 16, _p(S1), B * N + 9, B, H, N, N, sc, code, _st()),
+                  "attention_mx")
+    torch.cuda.synchronize()
+    assert torch.equal(S1.cpu()[:, :B * N], S2.cpu()[:, :B * N]), "scales differ"
+    a, b = Y1.cpu()[:, :Cn].clone(), Y2.cpu()[:, :Cn].clone()
+    a[(a & 0x7F) == 0] = 0
+    b[(b & 0x7F) == 0] = 0
+    # bf16: identical.  f16: hipcc rounds o / l to f16 in one step (v_fma_mixlo_f16) in one kernel and in two (fp32 product, then
+    # v_cvt_f16_f32) in the other; the rare values this moves across an e4m3 tie differ by ONE fp8 code (measured 3 of 13.4 M)
+    nd = int((a != b).sum())
+    assert nd <= (0 if dt == "bf16" else max(1, a.numel() // 1_000_000)), f"{nd} bytes differ"
+    assert int((a.to(torch.int16) - b.to(torch.int16)).abs().max()) <= 1
+    # too small a grid for the kernel that implements the epilogue: refused, not silently different
+    assert L.ldx_op_attention_mx(_p(q), 3 * Cn, _p(k), 3 * Cn, _p(v), 3 * Cn, _p(Y1), Cn + 16, _p(S1), B * N + 9, 1, 1, 100, 100, sc, code, _st()) != 0
