@@ -252,6 +252,9 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
  * W [N][K]); fp32 accumulation; act as ldx_kernels.h GemmArgs::act; outputs 16-bit C and / or fp32 Cf — or, with C8 / SC
  * (N % 128 == 0, no R / C / Cf), the result quantised in the epilogue exactly as ldx_op_mx_quant would quantise the 16-bit
  * C: the operand of the next block-scaled GEMM without a separate pass. */
+/* LayerNorm whose output is quantised as ldx_op_mx_quant would quantise the 16-bit Y (C % 128 == 0). */
+int ldx_op_layernorm_mx(const void* X, int ldx, int rows, int C, float eps, const float* gamma, const float* beta,
+                        void* Y8, int ldy8, void* S8, int s8_ld, int dtype, void* stream);
 /* Attention (head dim 128, no mask) whose output is quantised in the epilogue exactly as ldx_op_mx_quant would quantise the
  * 16-bit O [B*Nq][H*128]: O8 bytes (row stride ldo8) + scales uint32 [H][so_ld] (one word per row and head).  Needs
  * B * H * ceil(Nq / 128) >= 64 workgroups (smaller problems: ldx_op_attention + ldx_op_mx_quant). */

@@ -282,6 +282,15 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm");
 }
+int ldx_op_layernorm_mx(const void* X, int ldx_, int rows, int C, float eps, const float* gamma, const float* beta,
+                        void* Y8, int ldy8, void* S8, int s8_ld, int dtype, void* stream) {
+    if (!X || !Y8 || !S8 || !gamma || !beta || rows <= 0 || C % 128 || C > 4096 || ldx_ % 8 || ldy8 % 16 || ldy8 < C || s8_ld < rows) {
+        set_error("ldx_op_layernorm_mx: bad argument (C % 128, C <= 4096, ldy8 % 16, s8_ld >= rows)"); return LDX_EINVAL; }
+    LayerNormArgs a{X, ldx_, nullptr, 0, rows, C, eps, gamma, beta};
+    a.Y8 = Y8; a.ldy8 = ldy8; a.S8 = (uint32_t*)S8; a.s8_ld = s8_ld;
+    launch_layernorm(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_layernorm_mx");
+}
 int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O8, int ldo8, void* SO, int so_ld,
                         int B, int H, int Nq, int Mk, float scale, int dtype, void* stream) {
     AttnArgs a{};

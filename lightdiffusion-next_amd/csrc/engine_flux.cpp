@@ -192,20 +192,6 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         }
         release(ptok); release(ctx16);
 
-        auto ln_mod = [&](const char* name, Act Xin, Act Y, const float* shift, const float* scale, int rpb) {
-            Op o{}; o.kind = OP_LN; o.name = name;
-            LayerNormArgs& l = o.ln;
-            l.X = ptr(Xin); l.ldx = Xin.ld; l.Y = ptr(Y); l.ldy = Y.ld; l.rows = Xin.rows; l.C = C; l.eps = 1e-6f; l.gamma = nullptr; l.beta = nullptr;
-            l.scale = scale; l.shift = shift; l.mod_ld = fx_mod_total; l.rows_per_batch = rpb;
-            o.bytes = 2.0 * 2.0 * (double)Xin.rows * C; snprintf(o.klabel, sizeof(o.klabel), "ln_kernel");
-            ops.push_back(o);
-        };
-        auto rope = [&](const char* name, Act QKV, const float* qs, const float* ks, int tok0) {
-            Op o{}; o.kind = OP_FX_ROPE; o.name = name;
-            o.rp = QkRopeArgs{ptr(QKV), QKV.ld, QKV.rows, L, H, D, qs, ks, nullptr, nullptr, 1e-6f};
-            o.i0 = tok0;                                 // first token index of this slice in the pe tables
-            ops.push_back(o);
-        };
         // MX fp8 mode: an activation that feeds block linears gets an e4m3 shadow [B*L][K] + E8M0 scales [K/128][B*L], filled by
         // a quantise op in front of its consumers; the consumers then run the block-scaled MFMA GEMM on (shadow, MX weight).
         struct Q8 { char* y = nullptr; uint32_t* s = nullptr; int K = 0; };
@@ -215,6 +201,24 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         auto new_q8 = [&](int K) { Q8 q; q.K = K; const size_t o8 = a_alloc((size_t)RT * K), os = a_alloc((size_t)(K / 128) * RT * 4);
                                    q.y = (char*)arena + o8; q.s = (uint32_t*)((char*)arena + os); return q; };
         auto row_of = [&](const Act& base, const Act& v) { return (int)((v.off - base.off) / ((size_t)base.ld * 2)); };
+        // qo != null: the output goes to the MX shadow of the buffer Y lives in (returns true), not to Y
+        auto ln_mod = [&](const char* name, Act Xin, Act Y, const float* shift, const float* scale, int rpb, const Q8* qo = nullptr, const Act* obase = nullptr) {
+            Op o{}; o.kind = OP_LN; o.name = name;
+            LayerNormArgs& l = o.ln;
+            l.X = ptr(Xin); l.ldx = Xin.ld; l.Y = ptr(Y); l.ldy = Y.ld; l.rows = Xin.rows; l.C = C; l.eps = 1e-6f; l.gamma = nullptr; l.beta = nullptr;
+            l.scale = scale; l.shift = shift; l.mod_ld = fx_mod_total; l.rows_per_batch = rpb;
+            o.bytes = 2.0 * 2.0 * (double)Xin.rows * C; snprintf(o.klabel, sizeof(o.klabel), "ln_kernel");
+            const bool fused = fx_fp8 && qo && (fuse_mask & 4);
+            if (fused) { const int ro = row_of(*obase, Y); l.Y8 = qo->y + (size_t)ro * qo->K; l.ldy8 = qo->K; l.S8 = qo->s + ro; l.s8_ld = RT; }
+            ops.push_back(o);
+            return fused;
+        };
+        auto rope = [&](const char* name, Act QKV, const float* qs, const float* ks, int tok0) {
+            Op o{}; o.kind = OP_FX_ROPE; o.name = name;
+            o.rp = QkRopeArgs{ptr(QKV), QKV.ld, QKV.rows, L, H, D, qs, ks, nullptr, nullptr, 1e-6f};
+            o.i0 = tok0;                                 // first token index of this slice in the pe tables
+            ops.push_back(o);
+        };
         auto quant = [&](const char* name, const Act& base, const Act& v, const Q8& q, int ncols = 0) {      // v: a row slice of base; its first ncols columns (0 = all)
             Op o{}; o.kind = OP_MXQ; o.name = name;
             const int r0 = row_of(base, v), K = ncols ? ncols : q.K;
@@ -272,8 +276,8 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                            {&blk.txt, txt_rows(X, b), txt_rows(N1, b), txt_rows(QKV, b), txt_rows(AO, b), txt_rows(MLP, b), Lt, 0}};
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total;
-                    ln_mod("fx.d.norm1", s.x, s.n, m + s.w->mod_off + 0 * C, m + s.w->mod_off + 1 * C, s.rows);
-                    if (fx_fp8) quant("fx.d.q.norm1", N1, s.n, qN1);
+                    const bool lq = ln_mod("fx.d.norm1", s.x, s.n, m + s.w->mod_off + 0 * C, m + s.w->mod_off + 1 * C, s.rows, &qN1, &N1);
+                    if (fx_fp8 && !lq) quant("fx.d.q.norm1", N1, s.n, qN1);
                     lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
                     rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
                 }
@@ -282,8 +286,8 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
                     lin("fx.d.proj", AO, s.ao, qAO, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);        // x += gate1 * proj(attn)
-                    ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows);
-                    if (fx_fp8) quant("fx.d.q.norm2", N1, s.n, qN1);
+                    const bool lq = ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows, &qN1, &N1);
+                    if (fx_fp8 && !lq) quant("fx.d.q.norm2", N1, s.n, qN1);
                     lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2, &qMLP, &MLP);       // tanh-GELU
                     if (fx_fp8 && !fuse_gemm_q) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
                     lin("fx.d.mlp2", MLP, s.mlp, qMLP, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);     // x += gate2 * mlp(...)
@@ -298,8 +302,8 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             for (int b = 0; b < B; ++b) {
                 const float* m = fx_mod + (size_t)b * fx_mod_total + blk.mod_off;
                 Act xb = rows(X, b * L, L), nb = rows(N1, b * L, L), qb = rows(QKV, b * L, L), cb = rows(CAT, b * L, L);
-                ln_mod("fx.s.pre_norm", xb, nb, m + 0 * C, m + 1 * C, L);
-                if (fx_fp8) quant("fx.s.q.norm", N1, nb, qN1);
+                const bool lq = ln_mod("fx.s.pre_norm", xb, nb, m + 0 * C, m + 1 * C, L, &qN1, &N1);
+                if (fx_fp8 && !lq) quant("fx.s.q.norm", N1, nb, qN1);
                 lin("fx.s.lin1.qkv", N1, nb, qN1, blk.lin1_qkv, qb, Act{}, nullptr, L, 0);
                 lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2, &qCAT, &CAT);
                 rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);

@@ -108,6 +108,9 @@ struct LayerNormArgs {
     const float* gamma; const float* beta;
     const float* scale; const float* shift; int mod_ld; int rows_per_batch;
     int rms;                       // 1: T5LayerNorm (no mean subtraction, no beta): x * rsqrt(mean(x^2) + eps) * gamma
+    // Y8 != null (C % 32 == 0): the output is written as MX fp8 instead of 16-bit Y: bytes Y8[row][c] (row stride ldy8) and
+    // scales S8 in the GemmArgs::SA layout (row stride s8_ld), exactly what launch_mx_quant would produce from Y
+    void* Y8; int ldy8; uint32_t* S8; int s8_ld;
 };
 void launch_layernorm(const LayerNormArgs& a, DType dt, hipStream_t s);
 

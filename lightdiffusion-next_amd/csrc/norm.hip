@@ -279,6 +279,18 @@ __global__ __launch_bounds__(256) void ln_kernel(const LayerNormArgs p) {
                 if (p.scale) v = (1.0f + sc[e]) * v + sh[e];
                 o[e] = v;
             }
+            if (p.Y8) {          // MX fp8: a 32-element block = the chunks of 4 adjacent lanes (same i), C % 32 == 0 keeps quads uniform
+                float amax = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { o[e] = to_f32(from_f32<T>(o[e])); amax = fmaxf(amax, fabsf(o[e])); }
+                amax = fmaxf(amax, dpp_f<0xB1>(amax));
+                amax = fmaxf(amax, dpp_f<0x4E>(amax));
+                const int ex = mx_scale_e8m0(amax);
+                const float inv = mx_inv_scale(ex);
+                *(uint2*)((char*)p.Y8 + row * p.ldy8 + ch * 8) = make_uint2(mx_pack4(o[0] * inv, o[1] * inv, o[2] * inv, o[3] * inv),
+                                                                            mx_pack4(o[4] * inv, o[5] * inv, o[6] * inv, o[7] * inv));
+                if ((sub & 3) == 0) { const int kb = ch >> 2; ((uint8_t*)p.S8)[((long)(kb >> 2) * p.s8_ld + row) * 4 + (kb & 3)] = (uint8_t)ex; }
+            } else
             *(uint4*)(y + ch * 8) = pack8<T>(o);
         }
     }

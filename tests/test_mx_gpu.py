@@ -184,3 +184,27 @@ def test_attention_mx_output(ldx_lib, ldx, dt, B, H, N):
     assert int((a.to(torch.int16) - b.to(torch.int16)).abs().max()) <= 1
     # too small a grid for the kernel that implements the epilogue: refused, not silently different
     assert L.ldx_op_attention_mx(_p(q), 3 * Cn, _p(k), 3 * Cn, _p(v), 3 * Cn, _p(Y1), Cn + 16, _p(S1), B * N + 9, 1, 1, 100, 100, sc, code, _st()) != 0
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("rows,Cn", [(1000, 3072), (77, 256), (333, 1280), (64, 4096)])
+def test_layernorm_mx_output(ldx_lib, ldx, dt, rows, Cn):
+    """LayerNorm with the MX output epilogue == ldx_op_layernorm followed by ldx_op_mx_quant."""
+    L = ldx_lib
+    td, code = DT[dt]
+    g = torch.Generator().manual_seed(rows + Cn)
+    X = (torch.randn(rows, Cn, generator=g) * 3 + 0.5).to(td).cuda()
+    gm, bt = torch.randn(Cn, generator=g).cuda(), torch.randn(Cn, generator=g).cuda()
+    Y = torch.zeros(rows, Cn, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_layernorm(_p(X), Cn, _p(Y), Cn, rows, Cn, 1e-6, _p(gm), _p(bt), code, _st()), "ln")
+    Y2, S2 = quant_gpu(L, ldx, Y, Cn, code, ldy=Cn + 16, s_ld=rows + 3)
+    Y1 = torch.zeros(rows, Cn + 16, device="cuda", dtype=torch.uint8)
+    S1 = torch.zeros(Cn // 128, rows + 3, 4, device="cuda", dtype=torch.uint8)
+    ldx.lib.check(L.ldx_op_layernorm_mx(_p(X), Cn, rows, Cn, 1e-6, _p(gm), _p(bt), _p(Y1), Cn + 16, _p(S1), rows + 3, code, _st()), "ln_mx")
+    torch.cuda.synchronize()
+    assert torch.equal(S1.cpu(), S2.cpu()), "scales differ"
+    a, b = Y1.cpu()[:, :Cn].clone(), Y2.cpu()[:, :Cn].clone()
+    a[(a & 0x7F) == 0] = 0
+    b[(b & 0x7F) == 0] = 0
+    nd = int((a != b).sum())
+    assert nd <= (0 if dt == "bf16" else max(1, a.numel() // 1_000_000)), f"{nd} bytes differ"
