@@ -486,7 +486,8 @@ template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
         const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S);
-        if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
+        if (t.bm == 256 && t.bn == 128) launch_gemm_inst<T, 0, 256, 128, 4, true>(a, S, s);      // opt-in (LDX_TILE256)
+        else if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
         else if (t.bn == 160 && !a.C8) launch_gemm_inst<T, 0, 128, 160, 2, true>(a, S, s);
         else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
         return;
