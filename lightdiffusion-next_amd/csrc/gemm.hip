@@ -461,9 +461,9 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     // wave quantisation: 257..511 tiles of 128x128 put two workgroups on some CUs and one on the rest (the launch takes as
     // long as the doubly-loaded CUs); if 128x160 tiles fit one per CU, every CU runs a single, 1.25x larger tile instead
-    if (bn == 128 && N % 160 == 0 && splitk <= 1 && !getenv("LDX_NO_TILE160")) {
+    if (bn == 128 && N % 160 == 0 && splitk <= 2 && !getenv("LDX_NO_TILE160")) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t160 = (long)((M + 127) / 128) * (N / 160);
-        if (t128 > 256 && t128 < 512 && t160 <= 256) bn = 160;
+        if (t128 > 256 && t128 < 512 && t160 <= 256) bn = 160;      // with splitk == 2 (gemm_choose_splitk's one-per-CU rule): 2 x t160 <= 512 workgroups
     }
     const long tiles = (long)((M + 127) / 128) * ((N + bn - 1) / bn) * (splitk > 1 ? splitk : 1);
     // < 0.8 of one round of 2 workgroups x 256 CUs and a short K loop (latency-bound): go small.
@@ -521,6 +521,15 @@ int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     const int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     const int tiles = ((M + 127) / 128) * ((N + bn - 1) / bn);
     const int nk = K / BK;
+    // one workgroup per CU (193..256 tiles, or that many 160-wide ones) runs a long K loop alone: a CU advances two co-resident
+    // workgroups by one K-tile each in about the time a lone one needs for its own, so halving K for twice the workgroups nearly
+    // halves the launch; the fp32 partials + reduce pass cost ~15 us (64^2-level 3x3 convs 640 -> 640: 122 -> ~80 us)
+    static const bool split2 = !getenv("LDX_NO_SPLIT2");
+    if (split2 && K % BK == 0 && nk >= 60) {
+        const long mt = (M + 127) / 128;
+        const long t160 = (N % 160 == 0) ? mt * (N / 160) : 0;
+        if ((tiles > 192 && tiles <= 256) || (tiles > 256 && tiles < 512 && t160 > 192 && t160 <= 256)) return 2;
+    }
     // a split costs a second (reduce) launch of ~9 us: only worth it for long K (3x3 convs, FF down-projection)
     if (tiles >= 200 || nk < 40 || K % BK) return 1;
     int s = (440 + tiles / 2) / tiles;        // ~400-480 workgroups: 40 tiles -> 11 (measured best 10), 160 tiles -> 3
