@@ -749,6 +749,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
             case OP_GEMM: launch_gemm(o.g, dt, ls); break;
             case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
+            case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
             case OP_ATTN:
@@ -794,6 +795,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
                 else if (o.kind == OP_GN) snprintf(sh, sizeof(sh), " B%d HW%d C%d", o.gn.B, o.gn.HW, o.gn.C);
                 else if (o.kind == OP_LN) snprintf(sh, sizeof(sh), " R%d C%d", o.ln.rows, o.ln.C);
                 else if (o.kind == OP_MXQ) snprintf(sh, sizeof(sh), " R%d K%d", o.mq.rows, o.mq.K);
+                else if (o.kind == OP_GEMM2) snprintf(sh, sizeof(sh), " M%d+%d N%d K%d", o.g.M, o.g2.M, o.g.N, o.g.K);
                 key += sh;
             }
             ProfEntry& pe = prof[key];

@@ -249,6 +249,16 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 }
             }
         };
+        // merge the two plain GEMM ops just emitted (image stream, then text stream) into one two-problem launch
+        static const bool group2 = !(getenv("LDX_FLUX_GROUP") && atoi(getenv("LDX_FLUX_GROUP")) == 0);      // experiment switch
+        auto pair_last_two = [&](const char* name) {
+            if (!group2 || ops.size() < 2) return;
+            Op& A = ops[ops.size() - 2]; const Op& Bo = ops.back();
+            if (A.kind != OP_GEMM || Bo.kind != OP_GEMM || A.g.mode || Bo.g.mode || A.g.geglu || Bo.g.geglu || A.g.f8 != Bo.g.f8 ||
+                A.g.N != Bo.g.N || A.g.K != Bo.g.K) return;
+            A.kind = OP_GEMM2; A.name = name; A.g2 = Bo.g; A.g.splitk = A.g2.splitk = 1; A.flops += Bo.flops; A.bytes += Bo.bytes;
+            ops.pop_back();
+        };
         // returns true if the attention kernel wrote the MX shadow qo of obase itself (head dim 128, large grid)
         auto attn = [&](const char* name, Act QKV, Act O, const Q8* qo = nullptr, const Act* obase = nullptr) {
             const char* base = (const char*)ptr(QKV);
@@ -270,28 +280,38 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             if (blk_i == 1) fb_a_end = ops.size();
             ++blk_i;
             for (int b = 0; b < B; ++b) {
-                const float* mb = nullptr; (void)mb;
                 struct S { const FluxStreamW* w; Act x, n, qkv, ao, mlp; int rows; int tok0; };
                 S st[2] = {{&blk.img, img_rows(X, b), img_rows(N1, b), img_rows(QKV, b), img_rows(AO, b), img_rows(MLP, b), Li, Lt},
                            {&blk.txt, txt_rows(X, b), txt_rows(N1, b), txt_rows(QKV, b), txt_rows(AO, b), txt_rows(MLP, b), Lt, 0}};
+                // the image and the text stream run the same layer shapes on different weights: each pair of linears is one launch
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total;
                     const bool lq = ln_mod("fx.d.norm1", s.x, s.n, m + s.w->mod_off + 0 * C, m + s.w->mod_off + 1 * C, s.rows, &qN1, &N1);
                     if (fx_fp8 && !lq) quant("fx.d.q.norm1", N1, s.n, qN1);
-                    lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
-                    rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
                 }
+                for (S& s : st) lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
+                pair_last_two("fx.d.qkv x2");
+                for (S& s : st) rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
                 const bool aq = attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L), &qAO, &AO);          // joint [txt ; img] sequence
                 if (fx_fp8 && !aq) quant("fx.d.q.attn", AO, rows(AO, b * L, L), qAO);
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
                     lin("fx.d.proj", AO, s.ao, qAO, s.w->proj, s.x, s.x, m + 2 * C, s.rows, 0);        // x += gate1 * proj(attn)
+                }
+                pair_last_two("fx.d.proj x2");
+                for (S& s : st) {
+                    const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
                     const bool lq = ln_mod("fx.d.norm2", s.x, s.n, m + 3 * C, m + 4 * C, s.rows, &qN1, &N1);
                     if (fx_fp8 && !lq) quant("fx.d.q.norm2", N1, s.n, qN1);
-                    lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2, &qMLP, &MLP);       // tanh-GELU
-                    if (fx_fp8 && !fuse_gemm_q) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
+                }
+                for (S& s : st) lin("fx.d.mlp0", N1, s.n, qN1, s.w->mlp0, s.mlp, Act{}, nullptr, s.rows, 2, &qMLP, &MLP);       // tanh-GELU
+                pair_last_two("fx.d.mlp0 x2");
+                if (fx_fp8 && !fuse_gemm_q) for (S& s : st) quant("fx.d.q.mlp", MLP, s.mlp, qMLP);
+                for (S& s : st) {
+                    const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
                     lin("fx.d.mlp2", MLP, s.mlp, qMLP, s.w->mlp2, s.x, s.x, m + 5 * C, s.rows, 0);     // x += gate2 * mlp(...)
                 }
+                pair_last_two("fx.d.mlp2 x2");
             }
         }
         if (blk_i == 1) fb_a_end = ops.size();

@@ -33,8 +33,8 @@ template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 
 // F8: A / W are MX fp8 bytes (GemmArgs::f8): a K-tile is still 128 B per row = 128 elements, one 16x16x128 block-scaled MFMA
 // per (i, j) and K-tile instead of two 16x16x32; the E8M0 scales bypass LDS (one dword per row and K-tile, prefetched with
 // the tile).  Same LDS layout, staging, split-K and epilogue as the 16-bit kernel.
-template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
-__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
+template <typename T, int MODE, int BM, int BN, int WM, bool F8>
+__device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int block) {
     static_assert(!F8 || MODE == 0, "MX fp8 operands: plain GEMM only");
     constexpr int ES = F8 ? 1 : 2;              // bytes per A / W element
     constexpr int KE = 128 / ES;                // elements per K-tile (= BK for 16-bit)
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     const int tiles_m = (p.M + BM - 1) / BM;
     const int ntiles = tiles_m * tiles_n;
     const int S = p.splitk > 1 ? p.splitk : 1;
-    const int lin = xcd_remap(blockIdx.x, ntiles * S);
+    const int lin = xcd_remap(block, ntiles * S);
     const int bid = lin % ntiles, split = lin / ntiles;      // same-split tiles adjacent: neighbours share panels
     const int tm = bid / tiles_n, tn = bid % tiles_n;
     const int m0 = tm * BM, n0 = tn * BN;
@@ -395,6 +395,19 @@ __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const G
     }
 }
 
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
+__global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
+    gemm_tile_body<T, MODE, BM, BN, WM, F8>(p, blockIdx.x);
+}
+// Two independent plain GEMMs in one launch (Flux double blocks: the 4096-row image stream and the 256-row text stream run the
+// same layer shapes with different weights): the second problem's tiles are appended to the first's, so they fill the
+// partly empty last round of workgroups instead of running as a launch of their own at low occupancy.
+template <typename T, int BM, int BN, bool F8>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs a, const GemmArgs b, const int tiles_a) {
+    if ((int)blockIdx.x < tiles_a) gemm_tile_body<T, 0, BM, BN, 2, F8>(a, blockIdx.x);
+    else gemm_tile_body<T, 0, BM, BN, 2, F8>(b, blockIdx.x - tiles_a);
+}
+
 // sum the split-K partials (fixed order -> deterministic) and apply the epilogue; one thread per 4 columns
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
@@ -536,6 +549,23 @@ int gemm_choose_splitk(int M, int N, int K, bool geglu) {
     if (s > nk / 5) s = nk / 5;
     if (s > 16) s = 16;
     return s < 2 ? 1 : s;
+}
+
+template <typename T, bool F8>
+static void launch_gemm2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
+    const int ta = ((a.M + 127) / 128) * ((a.N + 127) / 128), tb = ((b.M + 127) / 128) * ((b.N + 127) / 128);
+    const size_t lds = 2 * stage_bytes<128, 128>();
+    static bool attr = false;
+    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm2_kernel<T, 128, 128, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    hipLaunchKernelGGL((gemm2_kernel<T, 128, 128, F8>), dim3(ta + tb), dim3(256), lds, s, a, b, ta);
+}
+// both plain mode, no split-K, no GEGLU, same operand kind (16-bit or MX); 128x128 tiles
+void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s) {
+    if (a.M <= 0 || a.N <= 0) { launch_gemm(b, dt, s); return; }
+    if (b.M <= 0 || b.N <= 0) { launch_gemm(a, dt, s); return; }
+    GemmArgs x = a, y = b; x.splitk = y.splitk = 1;
+    if (dt == DT_BF16) { if (a.f8) launch_gemm2_t<__bf16, true>(x, y, s); else launch_gemm2_t<__bf16, false>(x, y, s); }
+    else { if (a.f8) launch_gemm2_t<_Float16, true>(x, y, s); else launch_gemm2_t<_Float16, false>(x, y, s); }
 }
 
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {

@@ -53,6 +53,8 @@ struct GemmArgs {
                                    // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
 };
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
+// two independent plain GEMMs (mode 0, no split-K / GEGLU, both 16-bit or both MX) as one launch of 128x128 tiles
+void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s);
 int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
 
 // MX quantisation of a 16-bit [rows][K] matrix (row stride ldx): per 32-element block, scale = 2^ceil(log2(amax / 448))
