@@ -249,13 +249,12 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 }
             }
         };
-        // merge the two plain GEMM ops just emitted (image stream, then text stream) into one two-problem launch
+        // merge the two independent plain GEMM ops just emitted into one two-problem launch
         static const bool group2 = !(getenv("LDX_FLUX_GROUP") && atoi(getenv("LDX_FLUX_GROUP")) == 0);      // experiment switch
         auto pair_last_two = [&](const char* name) {
             if (!group2 || ops.size() < 2) return;
             Op& A = ops[ops.size() - 2]; const Op& Bo = ops.back();
-            if (A.kind != OP_GEMM || Bo.kind != OP_GEMM || A.g.mode || Bo.g.mode || A.g.geglu || Bo.g.geglu || A.g.f8 != Bo.g.f8 ||
-                A.g.N != Bo.g.N || A.g.K != Bo.g.K) return;
+            if (A.kind != OP_GEMM || Bo.kind != OP_GEMM || A.g.mode || Bo.g.mode || A.g.geglu || Bo.g.geglu || A.g.f8 != Bo.g.f8) return;
             A.kind = OP_GEMM2; A.name = name; A.g2 = Bo.g; A.g.splitk = A.g2.splitk = 1; A.flops += Bo.flops; A.bytes += Bo.bytes;
             ops.pop_back();
         };
@@ -326,6 +325,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 if (fx_fp8 && !lq) quant("fx.s.q.norm", N1, nb, qN1);
                 lin("fx.s.lin1.qkv", N1, nb, qN1, blk.lin1_qkv, qb, Act{}, nullptr, L, 0);
                 lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2, &qCAT, &CAT);
+                pair_last_two("fx.s.lin1 x2");                    // linear1's two halves (different epilogues) share the rounds of one launch
                 rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);
                 const bool aq = attn("fx.s.attn", qb, view(cb, 0, C), &qCAT, &CAT);
                 if (fx_fp8 && !(aq && fuse_gemm_q)) quant("fx.s.q.cat", CAT, cb, qCAT, fuse_gemm_q ? C : 0);
