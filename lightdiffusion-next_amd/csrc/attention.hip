@@ -319,11 +319,13 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 // 8*(s&1)..+7 of key tile s>>1 straight back as the P^T operand of k-step s makes k-slot 8h+e stand for key
 // 16s + (e < 4 ? 4h + e : 8 + 4h + e - 4); the V^T operand is gathered in exactly that order by two ds_read_b64_tr_b16 per
 // 16-lane group (keys 16s + 4h + 0..3 and 16s + 8 + 4h + 0..3, 16 d columns each).
-template <typename T, int KVB>       // KVB keys per LDS stage (64 or 128): one barrier + one staging round per KVB keys
+template <typename T, int KVB, int KROWB, int VROWB>       // KVB keys per LDS stage (64 or 128): one barrier + one staging round per KVB keys
 __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     constexpr int QW = 64, QB = 256;                 // queries per wave / workgroup
-    constexpr int ROWB = 160;                        // K and V rows: 48 / 64 (+ones) 16-bit values, padded; 160 = 32 (mod 64)
-    constexpr int KBYTES = KVB * ROWB, STAGE = 2 * KBYTES;
+    // LDS row strides (PMC: SQ_LDS_BANK_CONFLICT).  K rows are read 16 B per lane by 16 different rows at one chunk column: the
+    // stride must be an ODD number of 16-B chunks (9: 144 B).  V rows are read by ds_read_b64_tr_b16, 8 lanes x 8 B per row and
+    // 4 rows per 32-lane group: the four 64-B windows tile the 64 banks when the stride is 64 B times an odd number (3: 192 B).
+    constexpr int KBYTES = KVB * KROWB, VBYTES = KVB * VROWB, STAGE = KBYTES + VBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
 
     for (int i = tid; i < (2 * STAGE) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
     __syncthreads();
-    for (int i = tid; i < 2 * KVB; i += 256) *(T*)(smem + (i / KVB) * STAGE + KBYTES + (i % KVB) * ROWB + D * 2) = (T)1.0f;       // ones column of V at d = D
+    for (int i = tid; i < 2 * KVB; i += 256) *(T*)(smem + (i / KVB) * STAGE + KBYTES + (i % KVB) * VROWB + D * 2) = (T)1.0f;       // ones column of V at d = D
 
     // Q fragments (B operand): lane holds q = l31, d = 16*ks + 8*h2 .. +7
     V8 qf[2][3];
@@ -368,7 +370,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
     constexpr int NLD = (KVB * 6 + 255) / 256;       // up to 6 chunks per row (D <= 48)
     uint4 rk[NLD], rv[NLD];
-    int ko[NLD], vo[NLD], lo[NLD];
+    int ko[NLD], vo[NLD], lk[NLD], lv[NLD];
 #pragma unroll
     for (int i = 0; i < NLD; ++i) {
         const int idx = tid + i * 256;
@@ -376,7 +378,8 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         const bool in_tile = row < KVB;
         ko[i] = in_tile ? (row * p.ldk + ch * 8) * 2 : OOB;
         vo[i] = in_tile ? (row * p.ldv + ch * 8) * 2 : OOB;
-        lo[i] = in_tile ? row * ROWB + ch * 16 : -1;
+        lk[i] = in_tile ? row * KROWB + ch * 16 : -1;
+        lv[i] = in_tile ? KBYTES + row * VROWB + ch * 16 : -1;
     }
     const int kstep = KVB * p.ldk * 2, vstep = KVB * p.ldv * 2;
     auto gload = [&](int blk) {
@@ -393,7 +396,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         char* sB = smem + stage * STAGE;
 #pragma unroll
         for (int i = 0; i < NLD; ++i)
-            if (lo[i] >= 0) { *(uint4*)(sB + lo[i]) = rk[i]; *(uint4*)(sB + KBYTES + lo[i]) = rv[i]; }
+            if (lk[i] >= 0) { *(uint4*)(sB + lk[i]) = rk[i]; *(uint4*)(sB + lv[i]) = rv[i]; }
     };
 
     __syncthreads();
@@ -405,8 +408,8 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         const bool more = (blk + 1) < nblk;
         if (more) gload(blk + 1);
         auto process = [&](const int sub) __attribute__((always_inline)) {
-        const char* sK = smem + cur * STAGE + sub * 64 * ROWB;
-        const char* sV = smem + cur * STAGE + KBYTES + sub * 64 * ROWB;
+        const char* sK = smem + cur * STAGE + sub * 64 * KROWB;
+        const char* sV = smem + cur * STAGE + KBYTES + sub * 64 * VROWB;
         const int kv0 = blk * KVB + sub * 64;
 
         // ---- S^T = K Q^T : 2 key tiles x 2 query tiles x 3 k-steps ----
@@ -417,7 +420,7 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         for (int ks = 0; ks < 3; ++ks)
 #pragma unroll
             for (int kt = 0; kt < 2; ++kt) {
-                const V8 kf = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * ROWB + (2 * ks + h2) * 16));
+                const V8 kf = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * KROWB + (2 * ks + h2) * 16));
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) s[kt][qt] = mfma32(kf, qf[qt][ks], s[kt][qt]);
             }
@@ -480,10 +483,10 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
             for (int dt = 0; dt < 2; ++dt) {
                 // 16-lane group g16: h' = g16 >> 1, d columns dt*32 + 16*(g16 & 1) + 0..15; lane i of the group addresses 4 contiguous d
                 // of key (i >> 2) and receives column d = .. + i for keys K0 + 0..3
-                const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * ROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
+                const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * VROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
                 U128 vf;
                 vf.d[0] = lds_read_tr16(vp);
-                vf.d[1] = lds_read_tr16(vp + 8 * ROWB);
+                vf.d[1] = lds_read_tr16(vp + 8 * VROWB);
                 const V8 v8 = as_v8<T>(vf.u);
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma32(v8, pf[qt][st], o[qt][dt]);
@@ -521,18 +524,20 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     }
 }
 
-template <typename T, int KVB>
+template <typename T, int KVB, int KROWB, int VROWB>
 static void launch_attn32_k(const AttnArgs& a, hipStream_t s) {
-    const size_t lds = 2 * 2 * KVB * 160;
+    const size_t lds = 2 * KVB * (KROWB + VROWB);
     static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T, KVB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T, KVB, KROWB, VROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
     dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
-    hipLaunchKernelGGL((attn32_kernel<T, KVB>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn32_kernel<T, KVB, KROWB, VROWB>), grid, dim3(256), lds, s, a);
 }
 template <typename T>
 static void launch_attn32(const AttnArgs& a, hipStream_t s) {
     static const int kvb = getenv("LDX_ATTN32_KVB") ? atoi(getenv("LDX_ATTN32_KVB")) : 64;       // experiment switch
-    if (kvb == 128 && a.Mk >= 1024) launch_attn32_k<T, 128>(a, s); else launch_attn32_k<T, 64>(a, s);
+    // strides 160 / 160 had 2-way conflicts on every fragment read (SQ_LDS_BANK_CONFLICT 88.1 M -> 21.0 M cycles per launch with 144 / 192;
+    // same time at D = 40, which is VALU / MFMA bound)
+    if (kvb == 128 && a.Mk >= 1024) launch_attn32_k<T, 128, 144, 192>(a, s); else launch_attn32_k<T, 64, 144, 192>(a, s);
 }
 
 
@@ -542,11 +547,19 @@ static void launch_attn32(const AttnArgs& a, hipStream_t s) {
 // and V rows to 64*NDT + 32 B so that both fragment reads stay bank-conflict free.
 // ONES: denominator from a ones column of V (row D of O^T, needs D + 1 <= 32*NDT); otherwise (D a multiple of 32: the ones row would
 // cost a whole extra d tile) the fp32 P values are summed on the VALU per lane and the two halves are added once at the end.
+// LDS row strides of the generic kernel, same rules as attn32_kernel: K rows an odd number of 16-B chunks, V rows 64 B times an
+// odd number (LDX_G32_OLD_ROWS at build time restores the first layout for A/B)
+#ifdef LDX_G32_OLD_ROWS
+#define G32_KROW(NKS) (((NKS) & 1) ? (NKS) * 32 : (NKS) * 32 + 32)
+#define G32_VROW(NDT) ((NDT) * 64 + 32)
+#else
+#define G32_KROW(NKS) ((NKS) * 32 + 16)
+#define G32_VROW(NDT) (((NDT) & 1) ? (NDT) * 64 : (NDT) * 64 + 64)
+#endif
 template <typename T, int NKS, int NDT, int QT, bool ONES>
 __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     constexpr int QW = 32 * QT, QB = 4 * QW;
-    constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32;
-    constexpr int VROW = NDT * 64 + 32;
+    constexpr int KROW = G32_KROW(NKS), VROW = G32_VROW(NDT);
     constexpr int KBYTES = AT_KV * KROW, VBYTES = AT_KV * VROW, STAGE = KBYTES + VBYTES;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
@@ -790,7 +803,7 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
 
 template <typename T, int NKS, int NDT, int QT, bool ONES>
 static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
-    constexpr int KROW = (NKS & 1) ? NKS * 32 : NKS * 32 + 32, VROW = NDT * 64 + 32;
+    constexpr int KROW = G32_KROW(NKS), VROW = G32_VROW(NDT);
     const size_t lds = 2 * AT_KV * (KROW + VROW);
     static bool attr = false;
     if (!attr) { (void)hipFuncSetAttribute((const void*)attn32g_kernel<T, NKS, NDT, QT, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
