@@ -379,6 +379,88 @@ def sample_euler_cfgpp(model, x, sigmas, cfg_scale=7.5, cfg_min=1.0, s_extra_ste
     return x
 
 
+class BrownianIntervalNoise:
+    """Stand-in for sampling_util.BrownianTreeNoiseSampler (sampling_util.py:239-292; torchsde.BrownianTree, absent offline):
+    noise(sigma, sigma_next) = (W(sigma_next) - W(sigma)) / sqrt(|sigma_next - sigma|) for a Brownian motion W in sigma.
+    dpmpp_sde asks, per step, for [sigma_t, sigma_s] and then for the enclosing [sigma_t, sigma_next]; the second increment
+    reuses the first (W over [t, next] = W over [t, s] + an independent increment over [s, next]), so the two draws have
+    the joint law a Brownian tree gives them.  The individual numbers cannot match torchsde's (its tree and seeding are
+    not reproducible without the library): the sampler's arithmetic is pinned with this class injected on both sides.
+    Normal draws come from a CPU generator (seed given) or from the global CPU RNG (seed None)."""
+
+    def __init__(self, x, seed=None):
+        self.shape = tuple(x.shape)
+        self.gen = None if seed is None else torch.Generator().manual_seed(int(seed))
+        self._t0 = self._t1 = None
+        self._w = None
+
+    def _randn(self):
+        return torch.randn(self.shape, dtype=torch.float32, generator=self.gen)
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = float(sigma), float(sigma_next)
+        if self._t0 is not None and t0 == self._t0 and abs(t1 - t0) > abs(self._t1 - t0) and (t1 - t0) * (self._t1 - t0) > 0:
+            w = self._w + self._randn() * math.sqrt(abs(t1 - self._t1))      # extend [t0, s] to [t0, t1]
+        else:
+            w = self._randn() * math.sqrt(abs(t1 - t0))
+        self._t0, self._t1, self._w = t0, t1, w
+        return w / math.sqrt(abs(t1 - t0))
+
+
+@torch.no_grad()
+def sample_dpmpp_sde_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler=None, r=0.5, seed=None, enable_multiscale=True,
+                           multiscale_factor=0.5, multiscale_fullres_start=5, multiscale_fullres_end=8,
+                           multiscale_intermittent_fullres=False, trace=None):
+    """samplers.sample_dpmpp_sde_cfgpp (samplers.py:965-1254) with its defaults (r = 1/2).  As in the other cfgpp samplers the
+    CFG++ momentum branch is dead code: the sampler calls its own post-cfg hook with uncond_denoised = None (:1137-1139,
+    :1209-1211), which resets old_uncond_denoised and returns the guider's CFG output, so cfg_denoised == denoised.  What
+    runs is DPM-Solver++(SDE): per step two model evaluations (at sigma_i and at the midpoint sigma_fn(s) in log-sigma),
+    each followed by an ancestral split (sampling_util.get_ancestral_step) and a noise injection; the last step
+    (sigma_next == 0) is one Euler step.  Low-resolution steps evaluate BOTH model calls at the reduced size (:1186)."""
+    assert r == 0.5, "the reference never changes r; (1 - 1/(2r)) = 0 is assumed"
+    n_steps = len(sigmas) - 1
+    if n_steps < 1:
+        return x
+    ms = _Multiscale(x.shape, n_steps, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                     multiscale_fullres_end, multiscale_intermittent_fullres)
+    if noise_sampler is None:
+        noise_sampler = BrownianIntervalNoise(x, seed)
+
+    def denoise(xx, sigma, full):
+        """guider CFG output at the step's resolution, returned at full resolution"""
+        xp = xx if full else _bilinear(xx, (ms.scale_h, ms.scale_w))
+        if trace is not None:
+            trace.append(tuple(xp.shape[-2:]))
+        du, dc = model(xp, sigma)
+        d = torch.empty_like(xp)
+        _step(2, xp, du, dc, model.cfg, 0.0, 0.0, denoised_out=d)
+        return d if full else _bilinear(d, (ms.orig_h, ms.orig_w))
+
+    sigma_fn = lambda t: torch.exp(-t)       # noqa: E731
+    t_fn = lambda sg: -torch.log(sg)         # noqa: E731
+    for i in range(n_steps):
+        full = ms.fullres(i)
+        d1 = denoise(x, sigmas[i], full)
+        if sigmas[i + 1] == 0:
+            _step(0, x, d1, d1, 1.0, sigmas[i], sigmas[i + 1] - sigmas[i])                     # Euler on to_d (:1156-1159)
+            continue
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        s = t + (t_next - t) * r
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+        s_ = t_fn(sd)
+        x2 = x.clone()
+        _step(1, x2, d1, d1, 1.0, sigma_fn(s_) / sigma_fn(t), torch.expm1(t - s_))            # (sigma(s_)/sigma(t)) x - expm1(t - s_) d
+        nz = noise_sampler(sigma_fn(t), sigma_fn(s)).to(x.device, torch.float32).contiguous()
+        _step(3, x2, nz, nz, 1.0, s_noise * su, 0.0)
+        d2 = denoise(x2, sigma_fn(s), full)
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+        t_next_ = t_fn(sd)
+        _step(1, x, d2, d2, 1.0, sigma_fn(t_next_) / sigma_fn(t), torch.expm1(t - t_next_))
+        nz = noise_sampler(sigma_fn(t), sigma_fn(t_next)).to(x.device, torch.float32).contiguous()
+        _step(3, x, nz, nz, 1.0, s_noise * su, 0.0)
+    return x
+
+
 _MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -391,7 +473,7 @@ def _resolve_sampler(sampler_name):
     if sampler_name == "euler_cfgpp":
         return sample_euler_cfgpp, True
     if sampler_name == "dpmpp_sde_cfgpp":
-        raise NotImplementedError(f"sampler '{sampler_name}' (Brownian-tree noise, torchsde) is a next row (SURVEY §8 a5)")
+        return sample_dpmpp_sde_cfgpp, True
     return sample_euler, False
 
 

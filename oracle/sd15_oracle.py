@@ -410,6 +410,71 @@ def sample_euler_cfgpp(model_uc, x, sigmas, cfg, cfg_scale=7.5, cfg_min=1.0, tra
     return x
 
 
+class BrownianIntervalNoise:
+    """The build's stand-in for BrownianTreeNoiseSampler (sampling_util.py:239-292; torchsde is absent offline, so the
+    tree's own numbers are out of reach — "parity unpinned" for the noise values; the sampler arithmetic is pinned with
+    this class injected into the reference, oracle/ref_capture_sde.py).  (W(s1) - W(s0)) / sqrt|s1 - s0| of a Brownian
+    motion in sigma; a query that extends the previous interval from the same start reuses its increment."""
+
+    def __init__(self, x, seed=None):
+        self.shape = tuple(x.shape)
+        self.gen = None if seed is None else torch.Generator().manual_seed(int(seed))
+        self.t0 = self.t1 = self.w = None
+
+    def __call__(self, sigma, sigma_next):
+        t0, t1 = float(sigma), float(sigma_next)
+        z = torch.randn(self.shape, dtype=torch.float32, generator=self.gen)
+        if self.t0 is not None and t0 == self.t0 and abs(t1 - t0) > abs(self.t1 - t0) and (t1 - t0) * (self.t1 - t0) > 0:
+            w = self.w + z * math.sqrt(abs(t1 - self.t1))
+        else:
+            w = z * math.sqrt(abs(t1 - t0))
+        self.t0, self.t1, self.w = t0, t1, w
+        return w / math.sqrt(abs(t1 - t0))
+
+
+def sample_dpmpp_sde_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler=None, r=0.5, enable_multiscale=True,
+                           multiscale_factor=0.5, multiscale_fullres_start=5, multiscale_fullres_end=8,
+                           multiscale_intermittent_fullres=False, trace=None):
+    """samplers.sample_dpmpp_sde_cfgpp (samplers.py:965-1254).  The manual post-CFG hook calls (:1137-1139, :1209-1211)
+    return the guider's CFG output as "uncond_denoised" and reset old_uncond_denoised, so both cfg_denoised and
+    cfg_denoised_2 equal the plain CFG outputs and the momentum terms never run."""
+    n = len(sigmas) - 1
+    if n < 1:
+        return x
+    ms = Multiscale(x.shape, n, enable_multiscale, multiscale_factor, multiscale_fullres_start,
+                    multiscale_fullres_end, multiscale_intermittent_fullres)
+    if noise_sampler is None:
+        noise_sampler = BrownianIntervalNoise(x)
+    sigma_fn = lambda t: (-t).exp()            # noqa: E731   (:1081-1085)
+    t_fn = lambda sg: -sg.log()                # noqa: E731
+
+    def denoise(xx, sigma, full):
+        xp = xx if full else ms.down(xx)
+        if trace is not None:
+            trace.append(tuple(xp.shape[-2:]))
+        d = model(xp, sigma)
+        return d if full else ms.up(d)
+
+    for i in range(n):
+        full = ms.fullres(i)
+        denoised = denoise(x, sigmas[i], full)
+        if sigmas[i + 1] == 0:
+            x = x + ((x - denoised) / sigmas[i]) * (sigmas[i + 1] - sigmas[i])                  # :1156-1159
+            continue
+        t, t_next = t_fn(sigmas[i]), t_fn(sigmas[i + 1])
+        s = t + (t_next - t) * r
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(s), eta)
+        s_ = t_fn(sd)
+        x_2 = (sigma_fn(s_) / sigma_fn(t)) * x - (t - s_).expm1() * denoised + noise_sampler(sigma_fn(t), sigma_fn(s)) * s_noise * su
+        denoised_2 = denoise(x_2, sigma_fn(s), full)                                             # same resolution flag (:1186)
+        sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
+        t_next_ = t_fn(sd)
+        x = ((sigma_fn(t_next_) / sigma_fn(t)) * x
+             - (t - t_next_).expm1() * ((1 - 1 / (2 * r)) * denoised + (1 / (2 * r)) * denoised_2)
+             + noise_sampler(sigma_fn(t), sigma_fn(t_next)) * s_noise * su)
+    return x
+
+
 MULTISCALE_WHITELIST = ("dpmpp_sde_cfgpp", "sample_euler_ancestral", "sample_euler", "sample_dpmpp_2m_cfgpp")
 
 
@@ -431,7 +496,7 @@ def ksampler_sample(denoiser, seed, steps, cfg, sampler_name, scheduler, positiv
     elif sampler_name == "euler_cfgpp":
         fn, disable_cfg1 = sample_euler_cfgpp, True
     elif sampler_name == "dpmpp_sde_cfgpp":
-        raise NotImplementedError(sampler_name)
+        fn, disable_cfg1 = sample_dpmpp_sde_cfgpp, True
     else:
         fn, disable_cfg1 = sample_euler, False
     extra = {}
