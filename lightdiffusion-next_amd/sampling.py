@@ -423,8 +423,18 @@ def sample_dpmpp_sde_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler
         return x
     ms = _Multiscale(x.shape, n_steps, enable_multiscale, multiscale_factor, multiscale_fullres_start,
                      multiscale_fullres_end, multiscale_intermittent_fullres)
+    sigma_fn = lambda t: torch.exp(-t)       # noqa: E731
+    t_fn = lambda sg: -torch.log(sg)         # noqa: E731
+    # Default noise (BrownianIntervalNoise): the draws do not depend on x, so all of them are made up front, in the order the
+    # per-call sampler would make them (two per step with sigma_next > 0), and uploaded once; the Brownian combination
+    # (W[t,next] = W[t,s] + increment over [s,next]) becomes two noise-injection steps with host-computed coefficients.
+    # No host<->device synchronisation is left in the loop (the per-call path costs one blocking upload per evaluation).
+    pre = None
     if noise_sampler is None:
-        noise_sampler = BrownianIntervalNoise(x, seed)
+        ref = BrownianIntervalNoise(x, seed)
+        n_draw = 2 * sum(1 for i in range(n_steps) if float(sigmas[i + 1]) != 0.0)
+        pre = torch.stack([ref._randn() for _ in range(n_draw)]).to(x.device) if n_draw else None
+    k_draw = 0
 
     def denoise(xx, sigma, full):
         """guider CFG output at the step's resolution, returned at full resolution"""
@@ -436,8 +446,6 @@ def sample_dpmpp_sde_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler
         _step(2, xp, du, dc, model.cfg, 0.0, 0.0, denoised_out=d)
         return d if full else _bilinear(d, (ms.orig_h, ms.orig_w))
 
-    sigma_fn = lambda t: torch.exp(-t)       # noqa: E731
-    t_fn = lambda sg: -torch.log(sg)         # noqa: E731
     for i in range(n_steps):
         full = ms.fullres(i)
         d1 = denoise(x, sigmas[i], full)
@@ -450,14 +458,25 @@ def sample_dpmpp_sde_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_sampler
         s_ = t_fn(sd)
         x2 = x.clone()
         _step(1, x2, d1, d1, 1.0, sigma_fn(s_) / sigma_fn(t), torch.expm1(t - s_))            # (sigma(s_)/sigma(t)) x - expm1(t - s_) d
-        nz = noise_sampler(sigma_fn(t), sigma_fn(s)).to(x.device, torch.float32).contiguous()
-        _step(3, x2, nz, nz, 1.0, s_noise * su, 0.0)
+        if pre is not None:
+            z1, z2 = pre[k_draw], pre[k_draw + 1]
+            k_draw += 2
+            _step(3, x2, z1, z1, 1.0, s_noise * su, 0.0)                                       # W[t,s] / sqrt|s - t| = z1
+        else:
+            nz = noise_sampler(sigma_fn(t), sigma_fn(s)).to(x.device, torch.float32).contiguous()
+            _step(3, x2, nz, nz, 1.0, s_noise * su, 0.0)
         d2 = denoise(x2, sigma_fn(s), full)
         sd, su = get_ancestral_step(sigma_fn(t), sigma_fn(t_next), eta)
         t_next_ = t_fn(sd)
         _step(1, x, d2, d2, 1.0, sigma_fn(t_next_) / sigma_fn(t), torch.expm1(t - t_next_))
-        nz = noise_sampler(sigma_fn(t), sigma_fn(t_next)).to(x.device, torch.float32).contiguous()
-        _step(3, x, nz, nz, 1.0, s_noise * su, 0.0)
+        if pre is not None:
+            st, ss, sn = float(sigma_fn(t)), float(sigma_fn(s)), float(sigma_fn(t_next))
+            total = abs(sn - st)
+            _step(3, x, z1, z1, 1.0, float(s_noise * su) * math.sqrt(abs(ss - st) / total), 0.0)
+            _step(3, x, z2, z2, 1.0, float(s_noise * su) * math.sqrt(abs(sn - ss) / total), 0.0)
+        else:
+            nz = noise_sampler(sigma_fn(t), sigma_fn(t_next)).to(x.device, torch.float32).contiguous()
+            _step(3, x, nz, nz, 1.0, s_noise * su, 0.0)
     return x
 
 
