@@ -329,8 +329,12 @@ def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_s
     of the reference the noise is drawn here from the global CPU generator in the same order and uploaded (256 KiB
     per image and step)."""
     n_steps = len(sigmas) - 1
+    pre, k_draw = None, 0
     if noise_sampler is None:
-        noise_sampler = lambda s, sn: torch.randn(x.shape, dtype=torch.float32)      # noqa: E731
+        # the default draws do not depend on x: make them all up front in the loop's order and upload once (no blocking
+        # host->device copy per step)
+        n_draw = sum(1 for i in range(n_steps) if float(sigmas[i + 1]) > 0)
+        pre = torch.stack([torch.randn(x.shape, dtype=torch.float32) for _ in range(n_draw)]).to(x.device) if n_draw else None
     for i in range(n_steps):
         sigma_hat = sigmas[i]
         du, dc = model(x, sigma_hat)
@@ -339,7 +343,10 @@ def sample_euler_ancestral_cfgpp(model, x, sigmas, eta=1.0, s_noise=1.0, noise_s
         sigma_down, sigma_up = get_ancestral_step(sigmas[i], sigmas[i + 1], eta=eta)
         _step(0, x, du, dc, model.cfg, sigma_hat, sigma_down - sigma_hat)
         if sigmas[i + 1] > 0:
-            nz = noise_sampler(sigmas[i], sigmas[i + 1]).to(x.device, torch.float32).contiguous()
+            if pre is not None:
+                nz = pre[k_draw]; k_draw += 1
+            else:
+                nz = noise_sampler(sigmas[i], sigmas[i + 1]).to(x.device, torch.float32).contiguous()
             _step(3, x, nz, nz, 1.0, s_noise * sigma_up, 0.0)
     return x
 
