@@ -18,4 +18,5 @@ from .engine import UNetEngine, UNetConfig, VAEDecoderEngine, CLIPTextEngine, Fl
 VAEEngine = VAEDecoderEngine      # the same engine encodes when encoder.* weights are loaded
 from .weights import VAEConfig, CLIPConfig, FluxConfig, T5Config, ESRGANConfig  # noqa: F401
 from .hook import LdxUNetPatch  # noqa: F401
+from . import prompt  # noqa: F401
 from . import sampling, parallel, checkpoint  # noqa: F401
