@@ -112,6 +112,7 @@ Engine::~Engine() {
     for (void* p : dev_allocs) (void)hipFree(p);
     if (arena) (void)hipFree(arena);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
+    for (PlanSnap& s : plan_cache) { if (s.arena) (void)hipFree(s.arena); if (s.graph_exec) (void)hipGraphExecDestroy(s.graph_exec); }
 }
 
 int Engine::validate() const {
@@ -725,6 +726,36 @@ int Engine::plan(int B2, int h, int w, int Mc) {
     return LDX_OK;
 }
 
+void Engine::plan_stash() {
+    PlanSnap s;
+    s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.ops = std::move(ops); s.flops = flops; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
+    s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
+    s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
+    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den;
+    ops.clear(); arena = nullptr; arena_cap = 0; graph_exec = nullptr; graph_valid = false; warm = false; pB2 = ph = pw = pM = 0;
+    plan_cache.push_back(std::move(s));
+    if (plan_cache.size() > 4) {
+        PlanSnap& o = plan_cache.front();
+        if (o.arena) (void)hipFree(o.arena);
+        if (o.graph_exec) (void)hipGraphExecDestroy(o.graph_exec);
+        plan_cache.erase(plan_cache.begin());
+    }
+}
+bool Engine::plan_restore(int B2, int h, int w, int Mc) {
+    for (size_t i = 0; i < plan_cache.size(); ++i) {
+        PlanSnap& s = plan_cache[i];
+        if (s.B2 != B2 || s.h != h || s.w != w || s.M != Mc) continue;
+        ops = std::move(s.ops); flops = s.flops; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
+        gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
+        d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
+        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den;
+        pB2 = B2; ph = h; pw = w; pM = Mc;
+        plan_cache.erase(plan_cache.begin() + i);
+        return true;
+    }
+    return false;
+}
+
 int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
     if (op_end > ops.size()) op_end = ops.size();
     const bool prof_now = profiling && !prof_graph;
@@ -811,8 +842,11 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     HIP_OK(hipSetDevice(device));
     if (B2 != pB2 || h != ph || w != pw || Mc != pM) {
         HIP_OK(hipStreamSynchronize(st));
-        int rc = plan(B2, h, w, Mc);
-        if (rc) return rc;
+        if (pB2 > 0) plan_stash();
+        if (!plan_restore(B2, h, w, Mc)) {
+            int rc = plan(B2, h, w, Mc);
+            if (rc) return rc;
+        }
     }
     const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise);
     if (graph_mode && graph_valid && same) {

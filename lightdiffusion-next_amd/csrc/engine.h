@@ -202,6 +202,18 @@ private:
     bool mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r);
     void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc);
 
+    // UNet plans of other input shapes seen (multi-scale samplers alternate between two resolutions): launch plan, arena and
+    // captured graph are kept per shape, so switching back costs nothing (a re-plan + two eager passes before the graph is
+    // usable again cost ~17 ms per switch)
+    struct PlanSnap {
+        int B2 = 0, h = 0, w = 0, M = 0; std::vector<Op> ops; double flops = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
+        size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
+        hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
+        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false;
+    };
+    std::vector<PlanSnap> plan_cache;
+    void plan_stash();                    // move the current plan into plan_cache (evicting the oldest beyond 4)
+    bool plan_restore(int B2, int h, int w, int Mc);
     std::vector<hipEvent_t> prof_events;
     bool prof_graph = false;
     // graph replay
