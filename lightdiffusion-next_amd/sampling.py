@@ -538,7 +538,7 @@ class KSampler:
             x = noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)
         else:
             x = noise * sigmas[0]
-        x = (x + latent_image).to(dev)
+        x = x.to(dev) + latent_image.to(dev)                       # the latent may already live on the device (HiresFix chain)
         model = CFGDenoiser(self.engine, positive, negative, cfg, b, h, w, disable_cfg1_optimization=disable_cfg1)
         x = fn(model, x, sigmas, trace=trace, **extra)
         return x / 0.18215                                         # process_latent_out (CFG.py:294)

@@ -40,3 +40,23 @@ for name, sched, kw in (("dpmpp_sde_cfgpp", "karras", {}), ("euler", "normal", {
     c, s, v, n, ok = run(name, sched, **kw)
     print(f"{name:18s}/{sched:6s}: CLIP {c * 1e3:6.2f} ms | sampler {s * 1e3:7.1f} ms ({n} UNet evaluations, {n / s:5.1f} eval/s) | VAE decode {v * 1e3:5.1f} ms | "
           f"image {8 * lat}^2 in {(c + s + v):.3f} s  finite={ok}", flush=True)
+
+# ---- BASELINE config 5 shape: txt2img latents -> bislerp x2 -> 10 steps euler_ancestral_cfgpp / normal, denoise 0.45 at 2048^2
+#      (pipeline.py:346-366) -> VAE decode 2048^2 (untiled) ----
+if lat == 128 and os.environ.get("LDX_SKIP_HIRES", "0") != "1":
+    cond = clip.forward(ids, -2)
+    cond = cond[0] if isinstance(cond, (tuple, list)) else cond
+    pos, neg = cond[0:1].float(), cond[1:2].float()
+    base = ks.sample(seed=1, steps=20, cfg=7.0, sampler_name="dpmpp_sde_cfgpp", scheduler="karras", positive=pos, negative=neg,
+                     latent_image=torch.zeros(1, 4, lat, lat))
+    for rep in range(2):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        up = ldx.latent_upscale(base, 2 * 8 * lat, 2 * 8 * lat)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        hi = ks.sample(seed=2, steps=10, cfg=8.0, denoise=0.45, sampler_name="euler_ancestral_cfgpp", scheduler="normal", positive=pos, negative=neg,
+                       latent_image=up)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        img = vae.decode(hi)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+    print(f"HiresFix 2048^2: bislerp {1e3 * (t1 - t0):.1f} ms | 10 steps euler_ancestral_cfgpp (denoise 0.45 -> {len(ldx.sampling.sigmas_for(ks.model_sampling, 'normal', 10, 0.45)) - 1} evaluations) "
+          f"{1e3 * (t2 - t1):.0f} ms | VAE decode {1e3 * (t3 - t2):.0f} ms | total {(t3 - t0):.2f} s  finite={bool(torch.isfinite(img).all())}")
