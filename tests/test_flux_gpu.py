@@ -90,3 +90,35 @@ def test_flux_fp8_needs_multiple_of_128(ldx, ldx_lib):
     sd = ldx.weights.synth_state_dict(ldx.weights.flux_state_dict_spec(cfg), seed=31, dtype=torch.float32)
     with pytest.raises(Exception, match="multiples of 128"):
         ldx.FluxEngine(cfg, sd, device=0, dtype="bf16", fp8=True)
+
+
+def test_flux_mx_fp8_with_first_block_cache(ldx, ldx_lib):
+    """The two opt-in approximate modes together: the plan split of the first-block cache (snapshot, residual, early exit) on
+    the MX fp8 plan.  Thresholds far from the measured residual ratios make the hit / miss sequence unambiguous
+    (5.0: every forward after the first hits; 1e-6: none does); outputs vs the oracle running the same two modes."""
+    cfg = ldx.FluxConfig(in_channels=16, vec_in_dim=64, context_in_dim=128, hidden_size=256, num_heads=2, depth=2,
+                         depth_single_blocks=3, axes_dim=(16, 56, 56))
+    sd = ldx.weights.synth_state_dict(ldx.weights.flux_state_dict_spec(cfg), seed=5, dtype=torch.float32)
+    sd = {k: v.to(torch.float16).float() for k, v in sd.items()}
+    eng = ldx.FluxEngine(cfg, sd, device=0, dtype="f16", fp8=True)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(1, 16, 16, 24, generator=g); ctx = torch.randn(1, 40, 128, generator=g); y = torch.randn(1, 64, generator=g)
+    gd = torch.tensor([3.5])
+    ts = [0.9, 0.7, 0.5, 0.3]
+    for thr, want_hits in ((5.0, 3), (1e-6, 0)):
+        eng.set_fbcache(thr)
+        fb = O.FluxFBCache(thr)
+        worst = 0.0
+        for i, tv in enumerate(ts):
+            xi = x * (1.0 + 0.05 * i)
+            t = torch.tensor([tv])
+            out = eng.forward(xi.cuda(), t.cuda(), ctx.cuda(), y.cuda(), gd.cuda())
+            with torch.no_grad():
+                ref = O.flux_forward(sd, cfg, xi, t, ctx, y, gd, fb=fb, mx=True)
+            assert torch.isfinite(out).all()
+            worst = max(worst, _rel(out, ref))
+        st = eng.fbcache_stats()
+        print(f"fp8 + FBCache thr {thr}: hits {st['hits']} (oracle {sum(fb.log)}), worst rel-L2 {worst:.3e}")
+        assert st["hits"] == want_hits == sum(fb.log) and st["hits"] + st["misses"] == len(ts)
+        assert worst <= 4e-2
+    eng.set_fbcache(0.0)
