@@ -199,6 +199,40 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#ifndef LDX_GEMM_NO_T14
+    // Staging schedule (guide T14): the registers always hold the NEXT tile's loads.  Top of iteration kt: write tile kt+1 to the
+    // other LDS stage (its loads have had a whole iteration to land) and immediately re-issue the loads of tile kt+2, then compute
+    // tile kt; one barrier per K-tile.  Compared with load -> compute -> write -> barrier this keeps loads in flight across the
+    // barrier and overlaps the LDS write pass with the other waves' MFMAs.
+    int csa[F8 ? MI : 1], csb[F8 ? NJ : 1];              // the CURRENT tile's scales, own block's byte moved to bits 0..7
+    auto take_scales = [&]() {
+        if (F8) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) csa[i] = (int)(rsa[i] >> (8 * g4));
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) csb[j] = (int)(rsb[j] >> (8 * g4));
+        }
+    };
+    gload(0);
+    lstore(0);
+    take_scales();
+    if (nk > 1) gload(1);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int cur = kt & 1;
+        int nsa[F8 ? MI : 1], nsb[F8 ? NJ : 1];
+        if (kt + 1 < nk) {
+            lstore(cur ^ 1);
+            if (F8) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) nsa[i] = (int)(rsa[i] >> (8 * g4));
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) nsb[j] = (int)(rsb[j] >> (8 * g4));
+            }
+            if (kt + 2 < nk) gload(kt + 2);
+        }
+#else
     gload(0);
     lstore(0);
     __syncthreads();
@@ -214,6 +248,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
             for (int j = 0; j < NJ; ++j) csb[j] = (int)(rsb[j] >> (8 * g4));
         }
         if (more) gload(kt + 1);
+#endif
         const char* sA = smem + cur * STAGE_BYTES;
         const char* sB = sA + BM * BK * 2;
         if (F8) {
@@ -254,7 +289,16 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] = mfma16(bf[j], af[i], acc[i][j]);
         }
+#ifndef LDX_GEMM_NO_T14
+        if (F8 && kt + 1 < nk) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) csa[i] = nsa[i];
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) csb[j] = nsb[j];
+        }
+#else
         if (more) lstore(cur ^ 1);
+#endif
         __syncthreads();
     }
 
