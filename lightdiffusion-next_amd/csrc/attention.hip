@@ -639,13 +639,25 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     };
 
     __syncthreads();
+#ifndef LDX_ATTN_NO_T14
+    // staging schedule as in gemm.hip (guide T14): the registers hold the NEXT key block; it is written to the other stage at the top
+    // of an iteration, right after the barrier, and the loads of the block after it are re-issued before the compute phase.
+    // Same-box A/B: D = 128 0.315 -> 0.303 ms (Flux), D = 80 / 160 unchanged; the D = 40 kernel lost 1 % with it and keeps
+    // load -> compute -> write -> barrier
+    if (nblk > 0) { gload(0); lstore(0); if (nblk > 1) gload(1); }
+#else
     if (nblk > 0) { gload(0); lstore(0); }
+#endif
     __syncthreads();
 
     for (int blk = 0; blk < nblk; ++blk) {
         const int cur = blk & 1;
         const bool more = (blk + 1) < nblk;
+#ifndef LDX_ATTN_NO_T14
+        if (more) { lstore(cur ^ 1); if (blk + 2 < nblk) gload(blk + 2); }
+#else
         if (more) gload(blk + 1);
+#endif
         const char* sK = smem + cur * STAGE;
         const char* sV = sK + KBYTES;
         const int kv0 = blk * AT_KV;
@@ -738,7 +750,9 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
             }
         __builtin_amdgcn_s_setprio(0);
 
+#ifdef LDX_ATTN_NO_T14
         if (more) lstore(cur ^ 1);
+#endif
         __syncthreads();
     }
 

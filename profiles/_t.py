@@ -1,11 +1,8 @@
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from kprobe import gemm, conv
-gemm(8192, 8192, 8192, 5)
-gemm(4096, 12288, 3072, 20)
-gemm(32768, 320, 320, 50)
-gemm(8192, 640, 640, 50)
-gemm(2048, 1280, 5120, 50)
-conv(2, 128, 320, 320, 20)
-conv(2, 64, 640, 640, 20)
-conv(2, 32, 1280, 1280, 20)
+from kprobe import attn
+attn(reps=10)
+attn(B=1, H=24, N=4352, D=128, reps=20)
+attn(B=2, H=8, N=4096, D=80, reps=20)
+attn(B=2, H=8, N=1024, D=160, reps=20)
+attn(N=16384, M=77, reps=20)
