@@ -496,7 +496,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 // tile selection: {BM, BN}
 struct TileSel { int bm, bn; };
-static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
+static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, bool long_k_plain = false) {
     static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;      // experiment switch: BM*1000+BN
     if (force) return {force / 1000, force % 1000};
     if (!geglu && N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
@@ -505,7 +505,11 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk) {
     // what bounds the 128-row kernel there.  Needs about a full round of 256 workgroups and a well-filled last round.
     // Measured: +8..17 % on isolated large GEMMs / convs (operands L2/MALL-resident), but -2 % (Flux forward) to -6 % (VAE decode)
     // in the real launch sequences, where one workgroup per CU overlaps kernel tails worse: opt-in (LDX_TILE256=1).
-    static const bool use256 = getenv("LDX_TILE256") != nullptr;
+    // ... except very long K (>= 8192) plain 16-bit GEMMs, where the 256-row tile wins in the launch sequence too since the T14
+    // staging schedule (Flux single-block linear2, 4352 x 3072 x 15360: forward 98.2 -> 94.6 ms, same box); the MX kernel still
+    // loses with it on that shape (67.4 -> 69.7 ms)
+    static const bool env256 = getenv("LDX_TILE256") != nullptr;
+    const bool use256 = env256 || long_k_plain;
     if (use256 && splitk <= 1 && M >= 2048 && !(geglu && K < 1024)) {
         const long mt = (M + 255) / 256;
         auto eff = [&](int bn) { const long t = mt * ((N + bn - 1) / bn); return t < 230 ? 0.0 : (double)t / (double)(((t + 255) / 256) * 256); };
@@ -549,7 +553,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
         else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
         return;
     }
-    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
+    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S, MODE == 0 && a.K >= 8192);
     if (t.bm == 256 && t.bn == 160) launch_gemm_inst<T, MODE, 256, 160, 4>(a, S, s);
     else if (t.bm == 256) launch_gemm_inst<T, MODE, 256, 128, 4>(a, S, s);
     else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
