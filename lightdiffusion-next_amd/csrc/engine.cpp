@@ -251,9 +251,29 @@ bool Engine::mk_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     emb_total += Cout;
     emb_srcs.push_back({ew, eb, Cout});
     if (!mk_norm(pre + ".out_layers.0", Cout, r.gn2)) return false;
-    if (!mk_conv3(pre + ".out_layers.3", Cout, Cout, Cout, r.conv2)) return false;
     r.has_skip = Cin != Cout;
-    if (r.has_skip && !mk_linear(pre + ".skip_connection", Cout, Cin, true, r.skip, true)) return false;
+    const bool try_fuse = r.has_skip && Cin % 64 == 0 && !getenv("LDX_NO_FUSED_SKIP");
+    if (!try_fuse && !mk_conv3(pre + ".out_layers.3", Cout, Cout, Cout, r.conv2)) return false;
+    if (r.has_skip) {
+        // out = conv2(h) + skip_connection(x): one implicit GEMM over K = 9*Cout + Cin (GemmArgs::A2), weights [Cout][ky][kx][Cout | Cin]
+        const HostTensor* w2 = get(pre + ".out_layers.3.weight", {Cout, Cout, 3, 3});
+        const HostTensor* b2 = get(pre + ".out_layers.3.bias", {Cout});
+        const HostTensor* ws = get(pre + ".skip_connection.weight", {Cout, Cin, 1, 1});
+        const HostTensor* bs = get(pre + ".skip_connection.bias", {Cout});
+        if (try_fuse) {
+            if (!w2 || !b2 || !ws || !bs) return false;
+            r.fused_skip = true;
+            r.conv2.N = Cout; r.conv2.K = 9 * Cout + Cin;
+            r.conv2.w = upload16(Cout, (size_t)9 * Cout + Cin, [&](size_t rr, size_t c) {
+                if (c >= (size_t)9 * Cout) return ws->at(rr * Cin + (c - (size_t)9 * Cout));
+                const size_t tap = c / Cout, ci = c % Cout;
+                return w2->at((rr * Cout + ci) * 9 + tap);
+            });
+            r.conv2.b = upload32(Cout, [&](size_t i) { return b2->at(i) + bs->at(i); });
+            return r.conv2.w && r.conv2.b;
+        }
+        if (!mk_linear(pre + ".skip_connection", Cout, Cin, true, r.skip, true)) return false;
+    }
     return true;
 }
 
@@ -530,7 +550,11 @@ void Engine::emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W) {
     Act t3 = new_act(M, r.Cout);
     op_gn("res.gn2", t2, t3, B, H * W, r.gn2, r.eps, true);
     release(t2);
-    if (r.has_skip) {
+    if (r.has_skip && r.fused_skip) {
+        op_conv("res.conv2+skip", t3, B, H, W, r.Cout, r.conv2, 1, H, W, OUT, Act{});
+        GemmArgs& g = ops.back().g;
+        g.A2 = ptr(X); g.lda2 = X.ld; g.Cin2 = r.Cin;
+    } else if (r.has_skip) {
         Act t4 = new_act(M, r.Cout);
         op_gemm("res.skip", X, r.skip, t4, Act{});
         op_conv("res.conv2", t3, B, H, W, r.Cout, r.conv2, 1, H, W, OUT, t4);

@@ -27,7 +27,7 @@ struct HostTensor {
 struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0;
                  void* w8 = nullptr; uint32_t* sw = nullptr; };     // MX fp8 copy + E8M0 scales [K/128][N] (Flux fp8 mode)
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
-struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; int Cin = 0, Cout = 0; int emb_off = 0;
+struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; bool fused_skip = false; /* fused_skip: conv2 holds [W2 | Wskip], bias b2 + bskip */ int Cin = 0, Cout = 0; int emb_off = 0;
               float eps = 1e-5f; bool has_emb = true; };
 struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_off = 0; };
 struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };

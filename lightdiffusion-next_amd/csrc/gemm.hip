@@ -112,6 +112,14 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
             a_voff[j] = OOB;
         }
     }
+    __amdgpu_buffer_rsrc_t rA2;
+    int a2_voff[(MODE == 1) ? LA : 1];
+    if (MODE == 1 && p.A2) {
+        const long rem2 = ((long)(p.M - m0 - 1) * p.lda2 + p.Cin2) * 2;
+        rA2 = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.A2 + (long)m0 * p.lda2 * 2), 0, (int)(rem2 > 0x7fffffffL ? 0x7fffffffL : (rem2 > 0 ? rem2 : 0)), 0x00020000);
+#pragma unroll
+        for (int j = 0; j < LA; ++j) a2_voff[j] = (m0 + srow + RPP * j < p.M) ? ((srow + RPP * j) * p.lda2 + schunk * 8) * 2 : OOB;
+    }
     int w_voff[LB];
 #pragma unroll
     for (int j = 0; j < LB; ++j) {
@@ -139,7 +147,8 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
     bool st_new_tap = true;
     if (MODE == 1 && kt_begin > 0) {
         const int k0 = kt_begin * BK, tap = k0 / p.Cin;
-        st_ci = k0 - tap * p.Cin; st_ky = tap / 3; st_kx = tap - st_ky * 3;
+        if (tap >= 9) { st_ky = 3; st_kx = 0; st_ci = k0 - 9 * p.Cin; }      // inside the second-input segment
+        else { st_ci = k0 - tap * p.Cin; st_ky = tap / 3; st_kx = tap - st_ky * 3; }
     }
     auto ld128 = [](const __amdgpu_buffer_rsrc_t& r, int voff, int soff) {
         const auto v = __builtin_amdgcn_raw_buffer_load_b128(r, voff, soff, 0);
@@ -158,6 +167,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
         if (MODE == 0) {
 #pragma unroll
             for (int j = 0; j < LA; ++j) ra[j] = ld128(rA, kdead ? OOB : a_voff[j], k0 * ES);
+        } else if (st_ky == 3) {        // second input (GemmArgs::A2): plain rows, no window (wave-uniform branch)
+#pragma unroll
+            for (int j = 0; j < LA; ++j) ra[j] = ld128(rA2, a2_voff[j], st_ci * 2);
+            st_ci += BK;
         } else {
             if (st_new_tap) {           // wave-uniform: once per (ky,kx) tap
 #pragma unroll

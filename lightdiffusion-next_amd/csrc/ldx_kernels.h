@@ -30,6 +30,10 @@ struct GemmArgs {
     int Hv, Wv;                    // conv: virtual (resized) input extent seen by the 3x3 window
     int Hout, Wout, stride;        // conv: output extent
     int resize;                    // conv: 1 if (Hv,Wv) != (Hin,Win) -> nearest gather
+    // conv: optional second input read as a 10th "tap" (1x1, same pixel as the output row): K = 9*Cin + Cin2, W = [N][9*Cin | Cin2].
+    // ResBlock1's out = conv2(h) + skip_connection(x) (ResBlock.py:315-335) becomes ONE implicit GEMM: no separate 1x1 launch, no
+    // write + re-read of its result.  A2 rows are the output rows ([M][lda2]); stride 1 only.
+    const void* A2; int lda2; int Cin2;
     int pad0;                      // conv: 1 -> no top/left padding (VAE Downsample: F.pad (0,1,0,1) + stride-2 conv, VariationalAE.py:224-254)
     const float* bias;             // [N] or null
     const float* rowvec; int rowvec_ld; int rows_per_batch;   // per-batch channel vector or null
