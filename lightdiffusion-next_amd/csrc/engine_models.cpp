@@ -38,8 +38,26 @@ Engine::Engine(const ldx_clip_config& c, int dev) : cfg{}, device(dev) {
 bool Engine::mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     r.Cin = Cin; r.Cout = Cout; r.eps = 1e-6f; r.has_emb = false;
     if (!mk_norm(pre + ".norm1", Cin, r.gn1) || !mk_conv3(pre + ".conv1", Cout, Cin, Cin, r.conv1)) return false;
-    if (!mk_norm(pre + ".norm2", Cout, r.gn2) || !mk_conv3(pre + ".conv2", Cout, Cout, Cout, r.conv2)) return false;
+    if (!mk_norm(pre + ".norm2", Cout, r.gn2)) return false;
     r.has_skip = Cin != Cout;
+    if (r.has_skip && Cin % 64 == 0 && !getenv("LDX_NO_FUSED_SKIP")) {
+        // x = nin_shortcut(x); return x + h (ResBlock.py:383-406): folded into conv2 as a second K segment, like the UNet's ResBlock1
+        const HostTensor* w2 = get(pre + ".conv2.weight", {Cout, Cout, 3, 3});
+        const HostTensor* b2 = get(pre + ".conv2.bias", {Cout});
+        const HostTensor* ws = get(pre + ".nin_shortcut.weight", {Cout, Cin, 1, 1});
+        const HostTensor* bs = get(pre + ".nin_shortcut.bias", {Cout});
+        if (!w2 || !b2 || !ws || !bs) return false;
+        r.fused_skip = true;
+        r.conv2.N = Cout; r.conv2.K = 9 * Cout + Cin;
+        r.conv2.w = upload16(Cout, (size_t)9 * Cout + Cin, [&](size_t rr, size_t c) {
+            if (c >= (size_t)9 * Cout) return ws->at(rr * Cin + (c - (size_t)9 * Cout));
+            const size_t tap = c / Cout, ci = c % Cout;
+            return w2->at((rr * Cout + ci) * 9 + tap);
+        });
+        r.conv2.b = upload32(Cout, [&](size_t i) { return b2->at(i) + bs->at(i); });
+        return r.conv2.w && r.conv2.b;
+    }
+    if (!mk_conv3(pre + ".conv2", Cout, Cout, Cout, r.conv2)) return false;
     if (r.has_skip && !mk_linear(pre + ".nin_shortcut", Cout, Cin, true, r.skip, true)) return false;
     return true;
 }
