@@ -134,3 +134,24 @@ def test_fullwidth_flux_properties(ldx, ldx_lib):
     r = _rel(a8, a16)
     print(f"full-width Flux (1+1 blocks): MX fp8 vs bf16 rel-L2 {r:.3e}")
     assert r <= 6e-2
+
+
+def test_fullsize_clip_causality(ldx, ldx_lib):
+    """CLIP-L at full size (123 M synthetic parameters, 12 layers, 77 tokens): with the causal mask (clip/Clip.py:14-251) the
+    hidden states of positions < p cannot depend on the tokens at positions >= p — bit for bit, since the same kernels run on
+    the same rows — while the positions from p on must change."""
+    cfg = ldx.CLIPConfig()
+    sd = ldx.weights.synth_state_dict(ldx.weights.clip_state_dict_spec(cfg), seed=2)
+    clip = ldx.CLIPTextEngine(cfg, sd, device=0, dtype="bf16")
+    g = torch.Generator().manual_seed(6)
+    ids = torch.randint(1000, 40000, (2, 77), generator=g)
+    ids[:, 0] = 49406
+    ids2 = ids.clone()
+    p = 40
+    ids2[:, p:] = torch.randint(1000, 40000, (2, 77 - p), generator=g)
+    a = clip.forward(ids, -2); b = clip.forward(ids2, -2)
+    a = a[0] if isinstance(a, (tuple, list)) else a
+    b = b[0] if isinstance(b, (tuple, list)) else b
+    assert torch.isfinite(a).all()
+    assert torch.equal(a[:, :p], b[:, :p])
+    assert not torch.equal(a[:, p:], b[:, p:])
