@@ -155,3 +155,20 @@ def test_fullsize_clip_causality(ldx, ldx_lib):
     assert torch.isfinite(a).all()
     assert torch.equal(a[:, :p], b[:, :p])
     assert not torch.equal(a[:, p:], b[:, p:])
+
+
+def test_fullsize_vae_decode_properties(ldx, ldx_lib):
+    """VAE decoder at full size (49.5 M synthetic parameters) on a 1024^2 image (latent 128^2): deterministic, per-sample (a batch
+    of two decodes to the two single decodes bit for bit) and inside [0, 1] (process_output clamp, VariationalAE.py:595-597)."""
+    cfg = ldx.VAEConfig()
+    sd = ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(cfg), seed=1, dtype=torch.float32)
+    vae = ldx.VAEDecoderEngine(cfg, sd, device=0, dtype="bf16")
+    g = torch.Generator().manual_seed(8)
+    z = torch.randn(2, 4, 128, 128, generator=g).cuda()
+    both = vae.decode(z).clone()
+    assert both.shape == (2, 1024, 1024, 3) and torch.isfinite(both).all()
+    assert float(both.min()) >= 0.0 and float(both.max()) <= 1.0
+    assert torch.equal(both, vae.decode(z))
+    a = vae.decode(z[:1]).clone()
+    b = vae.decode(z[1:]).clone()
+    assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
