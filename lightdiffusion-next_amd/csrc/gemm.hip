@@ -476,10 +476,25 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = n + 3 < p.N;
-        for (int sidx = 0; sidx < p.splitk; ++sidx) {
-            const float* w = p.ws + ((size_t)sidx * p.M + m) * p.N + n;
-            if (full) { const float4 t = *(const float4*)w; v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
-            else for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += w[r];
+        if (full) {
+            // four partial loads in flight at a time (the adds stay in split order: deterministic)
+            int sidx = 0;
+            const size_t stride = (size_t)p.M * p.N;
+            const float* w = p.ws + (size_t)m * p.N + n;
+            for (; sidx + 4 <= p.splitk; sidx += 4) {
+                const float4 t0 = *(const float4*)(w + (size_t)sidx * stride), t1 = *(const float4*)(w + (size_t)(sidx + 1) * stride);
+                const float4 t2 = *(const float4*)(w + (size_t)(sidx + 2) * stride), t3 = *(const float4*)(w + (size_t)(sidx + 3) * stride);
+                v[0] += t0.x; v[1] += t0.y; v[2] += t0.z; v[3] += t0.w;
+                v[0] += t1.x; v[1] += t1.y; v[2] += t1.z; v[3] += t1.w;
+                v[0] += t2.x; v[1] += t2.y; v[2] += t2.z; v[3] += t2.w;
+                v[0] += t3.x; v[1] += t3.y; v[2] += t3.z; v[3] += t3.w;
+            }
+            for (; sidx < p.splitk; ++sidx) { const float4 t = *(const float4*)(w + (size_t)sidx * stride); v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w; }
+        } else {
+            for (int sidx = 0; sidx < p.splitk; ++sidx) {
+                const float* w = p.ws + ((size_t)sidx * p.M + m) * p.N + n;
+                for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += w[r];
+            }
         }
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
