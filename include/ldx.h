@@ -257,7 +257,7 @@ int ldx_op_layernorm_mx(const void* X, int ldx, int rows, int C, float eps, cons
                         void* Y8, int ldy8, void* S8, int s8_ld, int dtype, void* stream);
 /* Attention (head dim 128, no mask) whose output is quantised in the epilogue exactly as ldx_op_mx_quant would quantise the
  * 16-bit O [B*Nq][H*128]: O8 bytes (row stride ldo8) + scales uint32 [H][so_ld] (one word per row and head).  Needs
- * B * H * ceil(Nq / 128) >= 64 workgroups (smaller problems: ldx_op_attention + ldx_op_mx_quant). */
+ * B * H * ceil(Nq / 128) >= 16 workgroups (smaller problems: ldx_op_attention + ldx_op_mx_quant). */
 int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O8, int ldo8, void* SO, int so_ld,
                         int B, int H, int Nq, int Mk, float scale, int dtype, void* stream);
 int ldx_op_mx_quant(const void* X, int ldx, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream);

@@ -298,7 +298,7 @@ int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const vo
     a.O8 = O8; a.ldo8 = ldo8; a.SO = (uint32_t*)SO; a.so_ld = so_ld;
     if (!Q || !K || !V || !O8 || !SO || B <= 0 || H <= 0 || Nq <= 0 || Mk <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo8 % 16 || ldo8 < H * 128 || so_ld < B * Nq) {
         set_error("ldx_op_attention_mx: bad argument"); return LDX_EINVAL; }
-    if (!attention_mx_out_ok(a)) { set_error("ldx_op_attention_mx: needs head dim 128 and at least 64 query blocks of 128 (B * H * ceil(Nq / 128))"); return LDX_EINVAL; }
+    if (!attention_mx_out_ok(a)) { set_error("ldx_op_attention_mx: needs head dim 128 and at least 16 query blocks of 128 (B * H * ceil(Nq / 128))"); return LDX_EINVAL; }
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention_mx");
 }
