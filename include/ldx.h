@@ -268,6 +268,10 @@ int ldx_op_conv3x3(const void* X, int ldx, const void* W, int B, int Hin, int Wi
                    int stride, int Hout, int Wout, int resize_to_out, const float* bias,
                    const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,
                    int dtype, void* stream);
+/* ResBlock1 tail (ResBlock.py:315-335) as ONE implicit GEMM: Y = conv3x3(X, W[:, :9*Cin]) + X2 W[:, 9*Cin:]^T + bias, i.e. conv2(h) +
+ * skip_connection(x) with W = [Cout][ky][kx][Cin | Cin2] and the two biases summed; stride 1, pad 1, X2 rows = output rows. */
+int ldx_op_conv3x3_skip(const void* X, int ldx, const void* X2, int ldx2, int Cin2, const void* W, int B, int H, int Wd, int Cin, int Cout,
+                        const float* bias, void* Y, int ldy, int dtype, void* stream);
 int ldx_op_groupnorm(const void* X, int ldx, void* Y, int ldy, int B, int HW, int C, int G, float eps, int silu,
                      const float* gamma, const float* beta, float* workspace, int dtype, void* stream);
 int64_t ldx_op_groupnorm_workspace_floats(int B, int G);

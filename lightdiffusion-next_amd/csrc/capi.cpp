@@ -344,6 +344,19 @@ int ldx_op_conv3x3(const void* X, int ldx_, const void* W, int B, int Hin, int W
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_conv3x3");
 }
+int ldx_op_conv3x3_skip(const void* X, int ldx_, const void* X2, int ldx2, int Cin2, const void* W, int B, int H, int Wd, int Cin, int Cout,
+                        const float* bias, void* Y, int ldy, int dtype, void* stream) {
+    if (!X || !X2 || !W || !Y || Cin % 64 || Cin2 % 64 || ldx_ % 8 || ldx2 % 8 || B <= 0 || H <= 0 || Wd <= 0) {
+        set_error("ldx_op_conv3x3_skip: bad argument (Cin % 64, Cin2 % 64)"); return LDX_EINVAL; }
+    GemmArgs g{};
+    g.A = X; g.lda = ldx_; g.W = W; g.M = B * H * Wd; g.N = Cout; g.K = 9 * Cin + Cin2; g.mode = 1;
+    g.Cin = Cin; g.Hin = H; g.Win = Wd; g.Hout = H; g.Wout = Wd; g.stride = 1; g.Hv = H; g.Wv = Wd; g.resize = 0;
+    g.A2 = X2; g.lda2 = ldx2; g.Cin2 = Cin2;
+    g.bias = bias; g.rows_per_batch = H * Wd; g.C = Y; g.ldc = ldy;
+    if (int rc = attach_splitk(g)) return rc;
+    launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_conv3x3_skip");
+}
 int64_t ldx_op_groupnorm_workspace_floats(int B, int G) { return (int64_t)B * GN_NCHUNK * G * 2; }
 int ldx_op_groupnorm(const void* X, int ldx_, void* Y, int ldy, int B, int HW, int C, int G, float eps, int silu,
                      const float* gamma, const float* beta, float* workspace, int dtype, void* stream) {

@@ -98,6 +98,7 @@ _SIGS = {
     "ldx_op_conv3x3": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_groupnorm": (_i, [_vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp, _vp, _vp, _i, _vp]),
     "ldx_op_groupnorm_workspace_floats": (_i64, [_i, _i]),
+    "ldx_op_conv3x3_skip": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ldx_op_layernorm_mx": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_attention_mx": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ldx_op_mx_quant": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),

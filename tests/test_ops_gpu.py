@@ -126,6 +126,28 @@ def test_conv3x3(L, ldx, dt, case):
     _check(Y, ref, dt, what=f"conv {case}")
 
 
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("B,H,W,Cin,Cin2,Cout", [(2, 16, 16, 1280, 2560, 1280),     # split-K 11: several splits start inside the second segment
+                                                 (2, 32, 32, 640, 1280, 640), (1, 24, 20, 128, 64, 192), (2, 64, 64, 320, 640, 320)])
+def test_conv3x3_with_fused_skip(L, ldx, dt, B, H, W, Cin, Cin2, Cout):
+    """conv2(h) + skip_connection(x) of ResBlock1 as one implicit GEMM over K = 9*Cin + Cin2 (GemmArgs::A2)."""
+    td, code = DT[dt]
+    g = torch.Generator(device="cuda").manual_seed(B + H + Cin + Cin2)
+    X = torch.randn(B, H, W, Cin + 64, device="cuda", generator=g).to(td)
+    X2 = torch.randn(B, H, W, Cin2 + 8, device="cuda", generator=g).to(td)
+    W3 = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)).to(td)
+    W1 = (torch.randn(Cout, Cin2, device="cuda", generator=g) / math.sqrt(Cin2)).to(td)
+    Wp = torch.cat([W3.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin), W1], dim=1).contiguous()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    Y = torch.zeros(B * H * W, Cout, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_conv3x3_skip(_p(X), Cin + 64, _p(X2), Cin2 + 8, Cin2, _p(Wp), B, H, W, Cin, Cout, _p(bias), _p(Y), Cout, code, _st()),
+                  "conv+skip")
+    torch.cuda.synchronize()
+    ref = F.conv2d(X[..., :Cin].float().permute(0, 3, 1, 2), W3.float(), bias, padding=1)
+    ref = ref + F.conv2d(X2[..., :Cin2].float().permute(0, 3, 1, 2), W1.float()[:, :, None, None])
+    _check(Y, ref.permute(0, 2, 3, 1).reshape(B * H * W, Cout), dt, what="conv+skip")
+
+
 def test_conv3x3_image_over_2gib(L, ldx):
     """VAE decode at 2048^2 (config 5): one NHWC input image of 2048*2048*256 bf16 = 2 GiB.  The conv loader's buffer
     window is per tile, so rows whose byte offset exceeds 2^31 must still be right: check bands at the top, around the
