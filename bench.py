@@ -6,21 +6,39 @@ fused CFG + Euler update (ldx_sampler_step).  Full-size SD1.5 layout (859.5 M pa
 weights and inputs (no checkpoints offline), latent [1,4,128,128], 77-token contexts, cfg 7, sample_euler /
 normal schedule, multiscale off = SURVEY.md §8(d) config 2.  Inputs are resident in HBM before timing.
 
-N > 1: one process per GPU (torch.distributed, backend nccl = RCCL), each rank denoises its own latent
-(batch shard, bs = N total, weak scaling, no per-step collective); one all-gather of the final latents
-closes the timed region (north_star: "all-gather of decoded latents only").
+Launching.  `python bench.py --gpus N` with no torchrun environment re-executes itself under
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` (one process per GPU,
+backend nccl = RCCL over xGMI); under the driver's own torchrun launch it asserts WORLD_SIZE == --gpus, so a
+multi-GPU request can never silently run on one rank.
 
-Prints ONE JSON line on rank 0 (contract in the task prompt) with two extra objects:
-  roofline     — dominant kernel = the single (kernel, op shape) with the largest share of step time (the level-0
-                 self-attention, D = 40, 16384 tokens), algorithmic FLOP/s from per-op HIP events recorded on the launch
-                 stream (ldx_profile mode 2), against the dense bf16 MFMA peak (2.5 PFLOP/s, MI355X_MICROARCH.md); HBM
-                 traffic per launch from the committed PMC passes (profiles/r*/traffic.json); the per-class breakdown in
-                 `kernels`; plus whole-step achieved TFLOP/s (9.348 TFLOP/step).
-  cpu_baseline — the oracle (CPU restatement, kind "port") timed on this host's cores on a bounded sample.
+Workloads.
+  --config 2 (default)  one image per GPU: bs = N images in flight, weak scaling, no per-step collective; ONE
+                        all-gather of the final latents closes the timed region (north_star: "all-gather of decoded
+                        latents only").
+  --config 3            SURVEY §8(d) config 3: global batch 64 drawn by ONE prepare_noise(seed) call on the whole
+                        batch (ksampler_util.py:274-311), sharded 64/N per GPU (CFG batch 2*64/N), strong scaling.
+
+Timing.  W warm-up steps, then `--repeats` (default 3) timed regions of EXACTLY K steps each, every region bracketed
+by barrier + torch.cuda.synchronize() on both sides, MAX over ranks per region, median over regions -> `value`.
+
+Prints ONE JSON line on rank 0 (contract in the task prompt) with extra objects:
+  roofline      dominant kernel = the single (kernel, op shape) with the largest share of step time, algorithmic FLOP/s
+                from per-op HIP events recorded on the launch stream (ldx_profile mode 2) against the dense bf16 MFMA
+                peak (2.5 PFLOP/s, MI355X_MICROARCH.md); HBM traffic per launch from the committed PMC passes
+                (profiles/r*/traffic.json); per-class breakdown in `kernels`; whole-step achieved TFLOP/s.
+  cpu_baseline  the oracle (CPU restatement, kind "port") timed on this host's cores on the HEADLINE workload
+                (1024^2, CFG batch 2, >= 2 evaluations); `reference_cpu` carries the build-container measurement of the
+                reference's own path (tests/golden/unet_full.npz, written by oracle/ref_capture_full.py) — never mixed.
+  secondary     N = 1 only: the reference-default "euler" name (forced multi-scale, samplers.py:180-184) and the
+                end-to-end seconds per image (CLIP encode + 20 steps + VAE decode).
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -32,120 +50,294 @@ sys.path.insert(0, ROOT)
 PEAK_BF16_TFLOPS = 2500.0     # dense MFMA bf16, MI355X_MICROARCH.md "Chip-level parameters"
 
 
-def cpu_baseline(cfg, sd, budget_s=25.0):
-    """Oracle apply_model (CFG batch 2) on the host cores.  Tries 512^2 first, then the full 1024^2 workload
-    if one 512^2 evaluation took less than a quarter of the budget."""
-    from oracle import sd15_oracle as O      # baseline leg only — never on the product path
-    threads = torch.get_num_threads()
-    g = torch.Generator().manual_seed(7)
-    ctx = torch.randn([2, 77, cfg.context_dim], generator=g)
-    sdf = {k: v.float() for k, v in sd.items()}          # cast once (reference re-casts per call; excluded here)
-    result = None
-    for lat, label in ((64, "512x512"), (128, "1024x1024")):
-        x = torch.randn([2, 4, lat, lat], generator=g)
-        sig = torch.tensor([5.0, 5.0])
-        t0 = time.perf_counter()
-        with torch.no_grad():
-            O.apply_model(sdf, cfg, x, sig, ctx)
-        dt = time.perf_counter() - t0
-        result = {"value": round(1.0 / dt, 5), "unit": "it/s", "cores": threads, "kind": "port",
-                  "sample": f"1 CFG-batched UNet evaluation (oracle.apply_model, fp32) at {label}, batch 2, "
-                            f"{dt:.2f} s on {threads} torch threads of {os.cpu_count()} host cpus"}
-        if dt > budget_s / 4:
-            break
-    return result
-
-
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--repeats", type=int, default=3, help="timed regions of --steps steps each; the median is reported")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--latent", type=int, default=128)
-    ap.add_argument("--batch", type=int, default=1, help="images per GPU (default 1 = the headline config; 8 = the per-GPU shard of SURVEY config 3)")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3), help="SURVEY §8(d) config: 2 = one image per GPU (weak), 3 = global batch 64 sharded (strong)")
+    ap.add_argument("--global-batch", type=int, default=64, help="config 3 only")
+    ap.add_argument("--batch", type=int, default=1, help="config 2 only: images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet config")
-    args = ap.parse_args()
+    ap.add_argument("--stub-engine", action="store_true",
+                    help="TEST ONLY (tests/test_bench_gloo.py): CPU + gloo, an analytic per-sample stand-in for the UNet; the line is marked stub")
+    return ap.parse_args(argv)
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """No torchrun environment and N > 1: re-execute under torch.distributed.run, one rank per GPU."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
+# ------------------------------------------------------------------------------------------------------
+class StubEngine:
+    """TEST ONLY: strictly per-sample analytic denoiser on the CPU (no HIP) so that the N > 1 control flow of this file
+    (sharding, timed regions, gather, reductions, JSON) runs under gloo in the CPU test-suite."""
+    device = torch.device("cpu")
+
+    def denoise(self, x, sigma, ctx, out=None):
+        r = torch.tanh(x) / (1.0 + sigma.view(-1, 1, 1, 1)) + 1e-3 * ctx.mean(dim=(1, 2)).view(-1, 1, 1, 1)
+        if out is None:
+            return r
+        out.copy_(r)
+        return out
+
+    def set_graph_mode(self, on):
+        pass
+
+    def plan_info(self):
+        return {"launches": 0, "flops": 0.0, "arena_bytes": 0}
+
+
+def stub_step(x, du, dc, cfg, sigma, dt):
+    den = du + (dc - du) * cfg
+    x += ((x - den) / sigma) * dt
+
+
+# ------------------------------------------------------------------------------------------------------
+def cpu_baseline(cfg, sd, max_eval_s=150.0):
+    """Oracle apply_model (CFG batch 2, fp32) on the host cores: one evaluation at 512^2 (config 1 shape), then the
+    HEADLINE workload 1024^2: one untimed first touch is NOT spent (too slow); two timed evaluations, mean reported."""
+    from oracle import sd15_oracle as O      # baseline leg only — never on the product path
+    threads = torch.get_num_threads()
+    g = torch.Generator().manual_seed(7)
+    ctx = torch.randn([2, 77, cfg.context_dim], generator=g)
+    sdf = {k: v.float() for k, v in sd.items()}          # cast once (the reference re-casts per call; excluded here)
+    times = {}
+    for lat, n in ((64, 1), (128, 2)):
+        x = torch.randn([2, 4, lat, lat], generator=g)
+        sig = torch.tensor([5.0, 5.0])
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter()
+            with torch.no_grad():
+                O.apply_model(sdf, cfg, x, sig, ctx)
+            ts.append(time.perf_counter() - t0)
+            if ts[-1] > max_eval_s:
+                break
+        times[lat] = ts
+    t1024 = sum(times[128]) / len(times[128])
+    return {"value": round(1.0 / t1024, 5), "unit": "it/s", "cores": threads, "kind": "port",
+            "sample": f"{len(times[128])} CFG-batched UNet evaluations (oracle.apply_model, fp32, batch 2) at 1024x1024 = the headline "
+                      f"workload: {', '.join(f'{t:.1f}' for t in times[128])} s each on {threads} torch threads of {os.cpu_count()} host cpus; "
+                      f"512x512: {times[64][0]:.2f} s",
+            "s_per_it_1024": round(t1024, 2), "s_per_it_512": round(times[64][0], 2)}
+
+
+def reference_cpu():
+    """The reference's OWN path (model.apply_model / KSampler.sample imported from /root/reference), timed in the build
+    container when the full-width goldens were captured — carried as data, never re-measured on the GPU box."""
+    try:
+        import numpy as np
+        z = np.load(os.path.join(ROOT, "tests", "golden", "unet_full.npz"))
+        t = json.loads(str(z["timing_json"]))
+        return {"kind": "reference", "where": "build container (no GPU)", "cpus": t["cpus"], "torch_threads": t["torch_threads"],
+                "torch": t["torch"], "s_per_it_512": t.get("ks64_s_per_step"), "s_per_it_1024_first_call": t.get("am128_103_s"),
+                "it_per_s_512": round(1.0 / t["ks64_s_per_step"], 4) if t.get("ks64_s_per_step") else None,
+                "note": "fp16 weights, fp32 compute (manual_cast), CFG batch 2; 512^2 = mean of 4 sampler steps, 1024^2 = one apply_model call "
+                        "(oracle/ref_capture_full.py)"}
+    except Exception as e:          # fixture absent: say so instead of inventing a number
+        return {"kind": "reference", "error": repr(e)}
+
+
+def secondary_lines(ldx, unet, cfg, lat, steps):
+    """N = 1 extras of SURVEY §8(d): reference-default "euler" (forced multi-scale) and end-to-end seconds per image."""
+    vcfg = ldx.VAEConfig()
+    vae = ldx.VAEDecoderEngine(vcfg, ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(vcfg), seed=1, dtype=torch.float32), dtype="bf16")
+    ccfg = ldx.CLIPConfig()
+    clip = ldx.CLIPTextEngine(ccfg, ldx.weights.synth_state_dict(ldx.weights.clip_state_dict_spec(ccfg), seed=2), dtype="bf16")
+    ks = ldx.sampling.KSampler(unet)
+    ids = torch.randint(0, 49407, (2, 77), generator=torch.Generator().manual_seed(3))
+
+    def run(sampler, **kw):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        cond = clip.forward(ids, -2)
+        cond = cond[0] if isinstance(cond, (tuple, list)) else cond
+        pos, neg = cond[0:1].float(), cond[1:2].float()
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        trace = []
+        x = ks.sample(seed=1, steps=steps, cfg=7.0, sampler_name=sampler, scheduler="normal", positive=pos, negative=neg,
+                      latent_image=torch.zeros(1, 4, lat, lat), trace=trace, **kw)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        img = vae.decode(x)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        assert torch.isfinite(img).all()
+        return t1 - t0, t2 - t1, t3 - t2, trace
+
+    out = {}
+    for name, sampler, kw in (("euler_forced_multiscale", "euler", {}), ("sample_euler_e2e", "sample_euler", dict(enable_multiscale=False))):
+        run(sampler, **kw)                                   # warm: plans / graphs for both resolutions
+        rs = [run(sampler, **kw) for _ in range(3)]
+        samp = statistics.median(r[1] for r in rs)
+        tot = statistics.median(r[0] + r[1] + r[2] for r in rs)
+        trace = rs[0][3]
+        out[name] = {"sampler_name": sampler, "scheduler": "normal", "steps": steps, "it_per_s": round(steps / samp, 3),
+                     "unet_evaluations": len(trace), "evaluations_at_half_resolution": sum(1 for s in trace if s[0] != lat),
+                     "clip_ms": round(1e3 * statistics.median(r[0] for r in rs), 3), "sampler_ms": round(1e3 * samp, 2),
+                     "vae_decode_ms": round(1e3 * statistics.median(r[2] for r in rs), 2), "e2e_s_per_image": round(tot, 4),
+                     "runs": 3}
+    return out
+
+
+# ------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(self_launch(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"bench.py --gpus {args.gpus} is running with WORLD_SIZE={world}: refusing to mis-report n_gpus"
+    stub = args.stub_engine
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if stub:
+            dist_mod.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            torch.cuda.set_device(local_rank)
+            dist_mod.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         dist = dist_mod
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        assert dist.get_world_size() == args.gpus
+    if stub:
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local_rank)
+        dev = torch.device("cuda", local_rank)
+        sync = torch.cuda.synchronize
 
     import ldx_amd as ldx
     cfg = ldx.UNetConfig.tiny(64, 128) if args.tiny else ldx.UNetConfig.sd15()
-    spec = ldx.weights.unet_state_dict_spec(cfg)
-    sd = ldx.weights.synth_state_dict(spec, seed=1234)
-    eng = ldx.UNetEngine(cfg, sd, device=local_rank, dtype=args.dtype)
-    if not args.no_graph:
-        eng.set_graph_mode(True)
+    sd = None
+    if stub:
+        eng = StubEngine()
+    else:
+        spec = ldx.weights.unet_state_dict_spec(cfg)
+        sd = ldx.weights.synth_state_dict(spec, seed=1234)
+        eng = ldx.UNetEngine(cfg, sd, device=local_rank, dtype=args.dtype)
+        if not args.no_graph:
+            eng.set_graph_mode(True)
 
     lat = args.latent
+    if args.config == 3:
+        gb = args.global_batch
+        assert gb % world == 0, f"config 3: global batch {gb} must divide over {world} ranks"
+        pb, scaling = gb // world, "strong"
+    else:
+        pb, gb, scaling = args.batch, world * args.batch, "weak"
     total = args.warmup + args.steps
     ms = ldx.sampling.ModelSamplingDiscrete()
     sigmas = ldx.sampling.calculate_sigmas(ms, "normal", total)
     g = torch.Generator().manual_seed(7)
     pos = torch.randn([1, 77, cfg.context_dim], generator=g)
     neg = torch.randn([1, 77, cfg.context_dim], generator=g)
-    pb = args.batch
-    noise = ldx.parallel.shard_noise((world * pb, 4, lat, lat), 42, rank, world)              # config-3 style shard
+    # ONE draw for the whole global batch (reference semantics), then this rank's contiguous slice
+    noise = ldx.parallel.shard_noise((gb, 4, lat, lat), 42, rank, world)
+    assert noise.shape[0] == pb
     x = (noise * torch.sqrt(1.0 + sigmas[0] ** 2.0)).to(dev)
     model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, pb, lat, lat)
 
     def run_steps(i0, n):
         for i in range(i0, i0 + n):
             du, dc = model(x, sigmas[i])
-            ldx.sampling._step(0, x, du, dc, 7.0, sigmas[i], sigmas[i + 1] - sigmas[i])
+            if stub:
+                stub_step(x, du, dc, 7.0, sigmas[i], sigmas[i + 1] - sigmas[i])
+            else:
+                ldx.sampling._step(0, x, du, dc, 7.0, sigmas[i], sigmas[i + 1] - sigmas[i])
+
+    def fence():
+        sync()
+        if dist:
+            dist.barrier()
+        sync()
 
     run_steps(0, args.warmup)
-    torch.cuda.synchronize()
+    sync()
+    x_start = x.clone()
+    regions, gathers, gpu_ms = [], [], []
+    gathered = None
+    for rep in range(max(1, args.repeats)):
+        x.copy_(x_start)
+        fence()
+        if not stub:
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            ev0.record()
+        t0 = time.perf_counter()
+        run_steps(args.warmup, args.steps)
+        if not stub:
+            ev1.record()
+        sync()
+        tg0 = time.perf_counter()
+        gathered = ldx.parallel.gather_latents(x, gb, dist)    # final latents only: the job's single collective
+        sync()
+        tg1 = time.perf_counter()
+        fence()
+        regions.append(time.perf_counter() - t0)
+        gathers.append(tg1 - tg0)
+        if not stub:
+            gpu_ms.append(ev0.elapsed_time(ev1) / args.steps)
+    assert gathered.shape[0] == gb, (gathered.shape, gb)
+    assert torch.isfinite(gathered).all(), "non-finite latents"
+
+    # MAX over ranks per region; per-rank medians for the report
+    per_rank_ms = [1000.0 * statistics.median(regions) / args.steps]
     if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    run_steps(args.warmup, args.steps)
-    gathered = ldx.parallel.gather_latents(x, world, dist)    # final latents only: the job's single collective
-    assert gathered.shape[0] == world * pb
-    ev1.record()
-    torch.cuda.synchronize()
+        t = torch.tensor(regions + gathers, device=dev, dtype=torch.float64)
+        tmax = t.clone()
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        n = len(regions)
+        regions_max, gathers_max = tmax[:n].tolist(), tmax[n:].tolist()
+        mine = torch.tensor([per_rank_ms[0]], device=dev, dtype=torch.float64)
+        allr = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(allr, mine)
+        per_rank_ms = [float(v.item()) for v in allr]
+    else:
+        regions_max, gathers_max = regions, gathers
+    elapsed = statistics.median(regions_max)
+    # every rank must hold the same gathered batch: fold it into a checksum and compare across ranks
     if dist:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
-    if dist:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert torch.isfinite(x).all(), "non-finite latents"
+        cs = gathered.double().sum().reshape(1).to(dev)
+        lo, hi = cs.clone(), cs.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        assert float(lo.item()) == float(hi.item()), "ranks disagree on the gathered latents"
 
     info = eng.plan_info()
     # ---- per-kernel roofline leg: same process, same data, HIP events per op on the launch stream ----
     roof = None
-    if rank == 0:
+    if rank == 0 and not stub:
         eng.set_graph_mode(False)
         eng._lib.ldx_profile(eng._h, 2, 1)            # mode 2: keyed by kernel class AND op shape
-        xs = x.clone()
+        xs = x_start.clone()
         nprof = 3
         for i in range(nprof):
             du, dc = model(xs, sigmas[args.warmup])
         torch.cuda.synchronize()
         eng.profile(False, reset=False)
         rep = eng.profile_report()
+        if not args.no_graph:
+            eng.set_graph_mode(True)
         tot_ms = sum(v["ms"] for v in rep.values())
-        # per kernel class (shape suffix stripped) for the breakdown ...
         cls = {}
         for k, v in rep.items():
             c = k.split(" ")[0]
@@ -160,8 +352,8 @@ def main():
             if v["bytes"] > 0 and v["ms"] > 0:
                 e["alg_GBps"] = round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)
             kern[k] = e
-        # ... and the dominant KERNEL = the single (kernel, shape) with the most time: one launch geometry, so that "per launch"
-        # flops, duration and PMC traffic all refer to the same thing (the level-0 self-attention at 1024^2)
+        # the dominant KERNEL = the single (kernel, shape) with the most time: one launch geometry, so that "per launch"
+        # flops, duration and PMC traffic all refer to the same thing
         dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
         dv = rep[dom]
         dom_tflops = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
@@ -172,7 +364,7 @@ def main():
             traffic = json.load(open(tj)).get(dom, {}).get("bytes")      # HBM bytes per launch from the committed PMC passes
         except Exception:
             traffic = None
-        step_ms_gpu = ev0.elapsed_time(ev1) / args.steps
+        step_ms_gpu = statistics.median(gpu_ms)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
                 "launches_per_step": dv["count"] // nprof, "avg_launch_ms": round(dv["ms"] / dv["count"], 4),
@@ -183,28 +375,46 @@ def main():
                 "step_frac": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernels": kern}
 
+    secondary = None
+    if rank == 0 and world == 1 and not stub and not args.no_secondary and not args.tiny and args.config == 2 and pb == 1:
+        secondary = secondary_lines(ldx, eng, cfg, lat, args.steps)
+
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline and not args.tiny:
         cpu = cpu_baseline(cfg, sd)
+        cpu["reference_cpu"] = reference_cpu()
 
     if rank == 0:
-        value = world * args.steps / elapsed          # sampler iterations per second (each iteration advances `batch` images per GPU)
+        # config 2: N independent images advance one sampler iteration per step -> iterations/s summed over ranks (weak);
+        # config 3: the whole bs = 64 job advances one iteration per step (strong)
+        its = (world if args.config == 2 else 1) * args.steps / elapsed
+        headline = (args.config == 2 and pb == 1 and lat == 128 and not args.tiny and not stub)
         line = {
-            "metric": "sampler it/s (UNet steps/sec) SD1.5 1024x1024 bs=1 bf16",
-            "value": round(value, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": (round(value / 2.8, 3) if world == 1 else None), "dtype": args.dtype, "data": "synthetic",
+            "metric": ("STUB " if stub else "") + "sampler it/s (UNet steps/sec) SD1.5 1024x1024 bs=1 bf16",
+            "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
+            "vs_baseline": (round(its / 2.8, 3) if (world == 1 and headline) else None), "dtype": args.dtype,
+            "data": "stub (CPU test of the harness)" if stub else "synthetic",
             "config": {"workload": f"SD1.5 UNet (859.5M params, synthetic seeded weights) sampler loop, latent "
-                                   f"[{pb},4,{lat},{lat}] ({lat * 8}x{lat * 8}), CFG batch {2 * pb}, ctx 77x768, sample_euler/normal, "
-                                   f"multiscale off; per-GPU bs={pb}, {world * pb} image(s) in flight",
-                       "global_batch": world * pb, "images_per_gpu": pb, "image_steps_per_s": round(world * pb * args.steps / elapsed, 3),
-                       "parallelism": f"batch-shard x{world} (replicated weights, final all-gather)",
+                                   f"[{pb},4,{lat},{lat}] ({lat * 8}x{lat * 8}) per GPU, CFG batch {2 * pb}, ctx 77x768, sample_euler/normal, "
+                                   f"multiscale off; SURVEY config {args.config}: {gb} image(s) in flight over {world} GPU(s)",
+                       "survey_config": args.config, "global_batch": gb, "images_per_gpu": pb,
+                       "image_steps_per_s": round(gb * args.steps / elapsed, 3),
+                       "parallelism": f"batch-shard x{world} (replicated weights, one final all-gather of latents)",
                        "launches_per_step": info["launches"], "hip_graph": not args.no_graph,
                        "vs_baseline_note": "2.8 it/s = README table, RTX 3060 mobile + Stable-Fast (BASELINE.md §1)"},
-            "roofline": roof, "cpu_baseline": cpu,
+            "timing": {"repeats": len(regions_max), "statistic": "median of regions; each region = max over ranks",
+                       "region_ms_per_step": [round(1000.0 * r / args.steps, 3) for r in regions_max],
+                       "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
+                       "allgather_ms": round(1000.0 * statistics.median(gathers_max), 3),
+                       "allgather_bytes": int(gathered.numel() * 4),
+                       "backend": (dist.get_backend() if dist else None), "rccl_ranks": (dist.get_world_size() if dist else 1),
+                       "latents_sha256_16": hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]},
+            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if dist:
+        dist.barrier()
         dist.destroy_process_group()
 
 

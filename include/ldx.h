@@ -228,7 +228,9 @@ int ldx_flux_forward(ldx_engine* e, const float* x, const float* sigma, const fl
  * kind 0: Euler  x = x + ((x - d)/c0)*c1, c0 = sigma_hat, c1 = sigma_next - sigma_hat (samplers.py:308; util.py:26-37)
  * kind 1: DPM++ first order  x = c0*x - c1*d, c0 = sigma_next/sigma, c1 = expm1(-h)   (samplers.py:945-946)
  * kind 2: CFG combine only (denoised_out = d; x untouched) — low-resolution multiscale steps.
- * Same fp32 operation order as the reference expressions, no FMA contraction.  denoised_out may be NULL. */
+ * kind 3: noise injection  x = x + den_uncond * c0 (den_uncond = the noise tensor; samplers.py:723).
+ * Same fp32 operation order as the reference expressions, no FMA contraction.  denoised_out may be NULL for kinds
+ * 0, 1, 3; kind 2 REQUIRES it (LDX_EINVAL otherwise); kind 0 requires c0 != 0 (LDX_EINVAL otherwise). */
 int ldx_sampler_step(int kind, float* x, const float* den_uncond, const float* den_cond, float* denoised_out,
                      int64_t n, float cfg, float c0, float c1, void* stream);
 /* One pass of bislerp (src/Utilities/upscale.py:5-128; LatentUpscale for HiresFix, pipeline.py:346-366): slerp of the

@@ -527,8 +527,8 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
 template <typename T, int KVB, int KROWB, int VROWB>
 static void launch_attn32_k(const AttnArgs& a, hipStream_t s) {
     const size_t lds = 2 * KVB * (KROWB + VROWB);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32_kernel<T, KVB, KROWB, VROWB>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)attn32_kernel<T, KVB, KROWB, VROWB>, (int)lds);
     dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
     hipLaunchKernelGGL((attn32_kernel<T, KVB, KROWB, VROWB>), grid, dim3(256), lds, s, a);
 }
@@ -819,8 +819,8 @@ template <typename T, int NKS, int NDT, int QT, bool ONES>
 static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
     constexpr int KROW = G32_KROW(NKS), VROW = G32_VROW(NDT);
     const size_t lds = 2 * AT_KV * (KROW + VROW);
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn32g_kernel<T, NKS, NDT, QT, ONES>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)attn32g_kernel<T, NKS, NDT, QT, ONES>, (int)lds);
     constexpr int QB = 128 * QT;
     dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
     hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT, ONES>), grid, dim3(256), lds, s, a);
@@ -857,8 +857,8 @@ static void launch_attn_q(const AttnArgs& a, hipStream_t s) {
     constexpr int STAGE = AT_KV * (AttnCfg<KS, DT>::KROWB + AttnCfg<KS, DT>::VROWB);
     constexpr int QB = 64 * QT;
     const size_t lds = 2 * STAGE;
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)attn_kernel<T, KS, DT, QT>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)attn_kernel<T, KS, DT, QT>, (int)lds);
     dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
     hipLaunchKernelGGL((attn_kernel<T, KS, DT, QT>), grid, dim3(256), lds, s, a);
 }

@@ -1,5 +1,6 @@
 // extern "C" surface of libldx.so (include/ldx.h).  No exceptions cross the ABI.
 #include <cstring>
+#include <mutex>
 #include <new>
 
 #include "engine.h"
@@ -28,14 +29,22 @@ static int check_launch(const char* what) {
 }
 
 // scratch for the single-op entry points (split-K partials); grown on demand, never shrunk
+// One buffer PER DEVICE (the current one), growth under a mutex.  The single-op entry points are test / probe
+// surface: calls that split K share this buffer, so they must be issued on ONE stream per device at a time
+// (include/ldx.h says so); the engines own their workspaces and never come here.
 static float* op_workspace(size_t floats) {
-    static float* buf = nullptr; static size_t cap = 0;
-    if (floats > cap) {
-        if (buf) { (void)hipDeviceSynchronize(); (void)hipFree(buf); buf = nullptr; cap = 0; }
-        if (hipMalloc((void**)&buf, floats * 4) != hipSuccess) return nullptr;
-        cap = floats;
+    static std::mutex mu;
+    static float* buf[64] = {nullptr}; static size_t cap[64] = {0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    std::lock_guard<std::mutex> lock(mu);
+    if (floats > cap[dev]) {
+        if (buf[dev]) { (void)hipDeviceSynchronize(); (void)hipFree(buf[dev]); buf[dev] = nullptr; cap[dev] = 0; }
+        if (hipMalloc((void**)&buf[dev], floats * 4) != hipSuccess) return nullptr;
+        cap[dev] = floats;
     }
-    return buf;
+    return buf[dev];
 }
 static int attach_splitk(GemmArgs& g) {
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, g.geglu != 0);
@@ -242,6 +251,8 @@ int ldx_set_graph_mode(ldx_engine* e, int enable) {
 
 int ldx_sampler_step(int kind, float* x, const float* du, const float* dc, float* dout, int64_t n, float cfg, float c0, float c1, void* stream) {
     if (!x || !du || !dc || n < 0 || (kind < 0 || kind > 3)) { set_error("ldx_sampler_step: bad argument"); return LDX_EINVAL; }
+    if (kind == 2 && !dout) { set_error("ldx_sampler_step: kind 2 (CFG combine only) needs denoised_out"); return LDX_EINVAL; }
+    if (kind == 0 && c0 == 0.f) { set_error("ldx_sampler_step: kind 0 (Euler) divides by c0 = sigma_hat, which must be non-zero"); return LDX_EINVAL; }
     StepArgs a{x, du, dc, dout, (size_t)n, cfg, kind, c0, c1};
     launch_sampler_step(a, (hipStream_t)stream);
     return check_launch("ldx_sampler_step");

@@ -113,6 +113,8 @@ Engine::~Engine() {
     if (arena) (void)hipFree(arena);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (PlanSnap& s : plan_cache) { if (s.arena) (void)hipFree(s.arena); if (s.graph_exec) (void)hipGraphExecDestroy(s.graph_exec); }
+    for (hipEvent_t ev : prof_events) (void)hipEventDestroy(ev);
+    if (cap_stream) (void)hipStreamDestroy(cap_stream);
 }
 
 int Engine::validate() const {

@@ -551,7 +551,8 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
     // wave quantisation: 257..511 tiles of 128x128 put two workgroups on some CUs and one on the rest (the launch takes as
     // long as the doubly-loaded CUs); if 128x160 tiles fit one per CU, every CU runs a single, 1.25x larger tile instead
-    if (bn == 128 && N % 160 == 0 && splitk <= 2 && !getenv("LDX_NO_TILE160")) {
+    static const bool no160 = getenv("LDX_NO_TILE160") != nullptr;
+    if (bn == 128 && N % 160 == 0 && splitk <= 2 && !no160) {
         const long t128 = (long)((M + 127) / 128) * ((N + 127) / 128), t160 = (long)((M + 127) / 128) * (N / 160);
         if (t128 > 256 && t128 < 512 && t160 <= 256) bn = 160;      // with splitk == 2 (gemm_choose_splitk's one-per-CU rule): 2 x t160 <= 512 workgroups
     }
@@ -567,8 +568,8 @@ template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * stage_bytes<BM, BN>();
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm_kernel<T, MODE, BM, BN, WM, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)gemm_kernel<T, MODE, BM, BN, WM, F8>, (int)lds);
     hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
@@ -632,8 +633,8 @@ template <typename T, bool F8>
 static void launch_gemm2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     const int ta = ((a.M + 127) / 128) * ((a.N + 127) / 128), tb = ((b.M + 127) / 128) * ((b.N + 127) / 128);
     const size_t lds = 2 * stage_bytes<128, 128>();
-    static bool attr = false;
-    if (!attr) { (void)hipFuncSetAttribute((const void*)gemm2_kernel<T, 128, 128, F8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); attr = true; }
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)gemm2_kernel<T, 128, 128, F8>, (int)lds);
     hipLaunchKernelGGL((gemm2_kernel<T, 128, 128, F8>), dim3(ta + tb), dim3(256), lds, s, a, b, ta);
 }
 // both plain mode, no split-K, no GEGLU, same operand kind (16-bit or MX); 128x128 tiles
@@ -715,12 +716,12 @@ void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s) {
     dim3 grid((a.N + 15) / 16), block(256);
     const size_t lds = (size_t)4 * a.K * sizeof(float);
     if (dt == DT_BF16) {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static DevOnce once;
+    set_dyn_lds(once, (const void*)skinny_kernel<__bf16>, 160 * 1024);
         hipLaunchKernelGGL((skinny_kernel<__bf16>), grid, block, lds, s, a);
     } else {
-        static bool attr = false;
-        if (!attr) { (void)hipFuncSetAttribute((const void*)skinny_kernel<_Float16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+        static DevOnce once;
+    set_dyn_lds(once, (const void*)skinny_kernel<_Float16>, 160 * 1024);
         hipLaunchKernelGGL((skinny_kernel<_Float16>), grid, block, lds, s, a);
     }
 }

@@ -11,6 +11,18 @@ namespace ldx {
 
 enum DType : int { DT_BF16 = 0, DT_F16 = 1 };
 
+// One-time hipFuncSetAttribute(MaxDynamicSharedMemorySize) PER DEVICE (function attributes are per device: a process that
+// builds engines on two GPUs must raise the limit on both).  One DevOnce per launcher instantiation; bit = device ordinal.
+struct DevOnce { unsigned long long mask = 0; };
+inline void set_dyn_lds(DevOnce& once, const void* fn, int bytes) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&once.mask, __ATOMIC_RELAXED) & bit) return;
+    (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    __atomic_fetch_or(&once.mask, bit, __ATOMIC_RELAXED);
+}
+
 // ---------------------------------------------------------------------------------------------
 // GEMM / implicit-GEMM convolution:  C[M][N] = epilogue( A[M][K] * W[N][K]^T )
 // mode 0: A is a plain row-major matrix (row stride lda), K % 64 == 0.

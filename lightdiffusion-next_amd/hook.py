@@ -12,8 +12,8 @@ model_options, ModelPatcher.py:108).
 """
 import torch
 
-from .engine import UNetEngine
-from .weights import UNetConfig
+from .engine import FluxEngine, UNetEngine
+from .weights import FluxConfig, UNetConfig
 
 
 class LdxUNetPatch:
@@ -45,3 +45,41 @@ class LdxUNetPatch:
 
     def __deepcopy__(self, memo):
         return self      # the native engine is shared, never duplicated
+
+
+class LdxFluxPatch:
+    """The same hook for the Flux family.  BaseModel.apply_model (src/Model/ModelBase.py:72-133) receives the Flux
+    conditioning through the same `c` dict: `c_crossattn` = T5 context [B, Lt, 4096], `y` = pooled CLIP-L vector [B, 768]
+    and `guidance` [B] (Flux2.extra_conds, src/BlackForest/Flux.py:781-817); the wrapper returns the CONST-prediction
+    denoised latent x - Flux3(x, sigma, ctx, y, guidance) * sigma (src/sample/sampling.py:100-155).  Lifecycle identical to
+    LdxUNetPatch (callable(model_function, params), `.to()` returns self, deep-copy safe)."""
+
+    def __init__(self, engine: FluxEngine):
+        self.engine = engine
+
+    @classmethod
+    def from_state_dict(cls, state_dict, cfg: FluxConfig = None, device: int = 0, dtype: str = "bf16", fp8: bool = False):
+        return cls(FluxEngine(cfg or FluxConfig(), state_dict, device=device, dtype=dtype, fp8=fp8))
+
+    def __call__(self, model_function, params):
+        x, sigma, c = params["input"], params["timestep"], params["c"]
+        ctx, y = c.get("c_crossattn"), c.get("y")
+        if ctx is None or y is None:
+            raise ValueError("LdxFluxPatch: c['c_crossattn'] (T5 context) and c['y'] (pooled CLIP vector) are required")
+        guidance = c.get("guidance")
+        if guidance is None and self.engine.cfg.guidance_embed:
+            raise ValueError("LdxFluxPatch: this Flux checkpoint embeds guidance; c['guidance'] is required")
+        for k in ("c_concat", "control"):
+            if c.get(k) is not None:
+                raise NotImplementedError(f"LdxFluxPatch: conditioning '{k}' is outside the Flux hot path")
+        src_device = x.device
+        dev = self.engine.device
+        f = lambda t: None if t is None else t.to(dev, torch.float32)
+        out = self.engine.denoise(f(x), f(sigma), f(ctx), f(y), f(guidance))
+        return out if src_device == dev else out.to(src_device)
+
+    def to(self, device):
+        return self
+
+    def __deepcopy__(self, memo):
+        return self

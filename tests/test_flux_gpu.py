@@ -122,3 +122,27 @@ def test_flux_mx_fp8_with_first_block_cache(ldx, ldx_lib):
         assert st["hits"] == want_hits == sum(fb.log) and st["hits"] + st["misses"] == len(ts)
         assert worst <= 4e-2
     eng.set_fbcache(0.0)
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_flux_hook_contract(ldx, flux, golden_dir, dt, tol):
+    """LdxFluxPatch fed the arguments the reference passes at cond.py:254-263 during KSampler.sample(flux=True)
+    (recorded by oracle/ref_capture_flux_hook.py: input, timestep, c = {c_crossattn, y, guidance, transformer_options})."""
+    import copy
+    cfg, sd, _ = flux
+    h = np.load(os.path.join(golden_dir, "flux_hook.npz"))
+    assert str(h["c_keys"]) == "c_crossattn,guidance,transformer_options,y"
+    patch = ldx.LdxFluxPatch(ldx.FluxEngine(cfg, sd, device=0, dtype=dt))
+    assert copy.deepcopy(patch) is patch and patch.to("cuda") is patch
+    for i in range(int(h["n"])):
+        T = lambda k: torch.from_numpy(h[f"h{i}_{k}"])
+        params = {"input": T("input"), "timestep": T("timestep"),
+                  "c": {"c_crossattn": T("ctx"), "y": T("y"), "guidance": T("guidance"), "transformer_options": {}},
+                  "cond_or_uncond": list(h[f"h{i}_cou"])}
+        out = patch(None, params)
+        assert out.device.type == "cpu" and out.dtype == torch.float32 and len(out.chunk(2)) == 2
+        r = _rel(out, h[f"h{i}_out"])
+        print(f"[{dt}] Flux hook call {i}: rel-L2 {r:.3e}")
+        assert r <= tol
+    with pytest.raises(ValueError):
+        patch(None, {"input": T("input"), "timestep": T("timestep"), "c": {"c_crossattn": T("ctx")}, "cond_or_uncond": [1, 0]})

@@ -1,0 +1,116 @@
+"""The BENCHMARKED network (SD1.5 UNet at model_channels = 320, 859.5 M synthetic parameters) against numbers, not properties:
+
+* reference goldens captured by oracle/ref_capture_full.py (the reference's own model.apply_model / KSampler.sample imported
+  from /root/reference in the build container): apply_model at latent 64^2 (two sigmas) and at 128^2 = the headline shape,
+  and a 4-step sample_euler/normal KSampler.sample at 64^2 — tests/golden/unet_full.npz holds seeds-regenerable inputs'
+  outputs only;
+* the oracle (CPU restatement) run on this box at 64^2 against the same inputs.
+
+This is where the full-width planner decisions are checked against the reference for the first time: D = 40 / 80 / 160 heads
+(attn32 / attn32g kernels), 160-wide tiles, split-K rules, the fused skip-connection K segment at Cin 2560 / 1920 / 960 and the
+12 concat buffers.  Tolerances as everywhere: fp16-activation mode rel-L2 <= 4e-3, bf16 mode <= 2.5e-2 & cos >= 0.9995
+on one evaluation; <= 1e-2 / 5e-2 on sampler latents.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import sd15_oracle as O              # noqa: E402  (checker only)
+from oracle.ref_capture_full import inputs      # noqa: E402  (pure function of (lat, seed); imports nothing of the reference)
+
+
+def _rel(a, b):
+    a, b = a.double().cpu(), torch.as_tensor(b).double()
+    return float((a - b).norm() / b.norm())
+
+
+def _cos(a, b):
+    a, b = a.double().cpu().flatten(), torch.as_tensor(b).double().flatten()
+    return float(torch.dot(a, b) / (a.norm() * b.norm()))
+
+
+@pytest.fixture(scope="module")
+def full(ldx, ldx_lib, golden_dir):
+    cfg = ldx.UNetConfig.sd15()
+    sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234)
+    g = np.load(os.path.join(golden_dir, "unet_full.npz"))
+    eng = {dt: ldx.UNetEngine(cfg, sd, device=0, dtype=dt) for dt in ("bf16", "f16")}
+    return cfg, sd, g, eng
+
+
+CASES = [(64, 101), (64, 102), (128, 103)]
+
+
+@pytest.mark.parametrize("lat,seed", CASES)
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_apply_model_full_width_vs_reference(full, lat, seed, dt, tol):
+    cfg, sd, g, eng = full
+    x, ctx = inputs(lat, seed)
+    sigma = torch.from_numpy(g[f"am{lat}_{seed}_sigma"])
+    want = g[f"am{lat}_{seed}_out"]
+    got = eng[dt].denoise(x.cuda(), sigma.cuda(), ctx.cuda())
+    # compare eps = (x - denoised) / sigma too: at small sigma `denoised` is dominated by x itself
+    eps_got = (x - got.cpu()) / sigma.view(-1, 1, 1, 1)
+    eps_want = (x - torch.from_numpy(want)) / sigma.view(-1, 1, 1, 1)
+    r, c, re = _rel(got, want), _cos(got, want), _rel(eps_got, eps_want)
+    print(f"[{dt}] full-width apply_model lat {lat} sigma {float(sigma[0])}: rel-L2 {r:.3e} cos {c:.6f}  eps rel-L2 {re:.3e}")
+    assert r <= tol and c >= 0.9995
+    assert re <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_ksampler_full_width_vs_reference(full, ldx, dt, tol):
+    cfg, sd, g, eng = full
+    ks = ldx.sampling.KSampler(eng[dt])
+    out = ks.sample(seed=42, steps=4, cfg=7.0, sampler_name="sample_euler", scheduler="normal", enable_multiscale=False,
+                    positive=torch.from_numpy(g["ks64_P"]), negative=torch.from_numpy(g["ks64_N"]), latent_image=torch.zeros(1, 4, 64, 64))
+    r, c = _rel(out, g["ks64_out"]), _cos(out, g["ks64_out"])
+    print(f"[{dt}] full-width KSampler 4 steps at 64^2: rel-L2 {r:.3e} cos {c:.6f}")
+    assert r <= tol and c >= 0.999
+
+
+def test_full_width_vs_oracle_on_this_box(full):
+    """The CPU restatement at full width on the GPU box's host cores (a few seconds at 64^2) against the engine AND the golden."""
+    cfg, sd, g, eng = full
+    x, ctx = inputs(64, 101)
+    sigma = torch.from_numpy(g["am64_101_sigma"])
+    with torch.no_grad():
+        ref = O.apply_model(sd, cfg, x, sigma, ctx)
+    ro = _rel(ref, g["am64_101_out"])
+    print(f"oracle vs reference golden at full width: rel-L2 {ro:.3e}")
+    assert ro <= 1e-4
+    for dt, tol in (("f16", 4e-3), ("bf16", 2.5e-2)):
+        got = eng[dt].denoise(x.cuda(), sigma.cuda(), ctx.cuda())
+        r = _rel(got, ref)
+        print(f"[{dt}] engine vs oracle at full width: rel-L2 {r:.3e}")
+        assert r <= tol
+
+
+def test_config3_shard_shape_runs(full, ldx):
+    """SURVEY config 3's per-GPU shard: 8 images (CFG batch 16) at 1024^2 through the engine; the batch must be per-sample
+    independent (rows of the batch-16 evaluation equal a batch-2 evaluation of the same image within the bf16 forward
+    tolerance — other tile shapes) and finite."""
+    cfg, sd, g, eng = full
+    e = eng["bf16"]
+    gen = torch.Generator().manual_seed(9)
+    noise = ldx.parallel.shard_noise((64, 4, 128, 128), 42, 3, 8)            # rank 3 of 8: images 24..31 of ONE draw
+    assert noise.shape[0] == 8
+    full_draw = ldx.sampling.prepare_noise(torch.zeros(64, 4, 128, 128), 42)
+    assert torch.equal(noise, full_draw[24:32])
+    pos, neg = torch.randn(1, 77, 768, generator=gen), torch.randn(1, 77, 768, generator=gen)
+    x = (noise * 14.6).cuda()
+    model = ldx.sampling.CFGDenoiser(e, pos, neg, 7.0, 8, 128, 128)
+    du, dc = model(x, torch.tensor(14.6))
+    du, dc = du.clone(), dc.clone()
+    assert torch.isfinite(du).all() and torch.isfinite(dc).all()
+    one = ldx.sampling.CFGDenoiser(e, pos, neg, 7.0, 1, 128, 128)
+    for i in (0, 5):
+        u1, c1 = one(x[i:i + 1], torch.tensor(14.6))
+        eps8, eps1 = (x[i:i + 1] - dc[i:i + 1]) / 14.6, (x[i:i + 1] - c1) / 14.6
+        r = _rel(eps8, eps1.cpu())
+        print(f"config-3 shard image {i}: eps rel-L2 batch-16 vs batch-2 evaluation {r:.3e}")
+        assert r <= 2.5e-2
