@@ -25,6 +25,148 @@ constexpr int BK = 64;
 // that N = 320 / 960 / 1920 get with 128.
 template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
 
+// Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
+// Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
+template <typename T, int BM, int BN, int WM, int MI, int NJ>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
+                                              const int l15, const int g4, const int split, const int S) {
+    // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
+    if (S > 1) {
+        float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
+    // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
+    if (p.C8) {
+        if constexpr ((BN / 2) % 32 == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+                const bool live = m < p.M;                      // no early exit: every lane takes part in the exchanges
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    const int n = n0 + wn * (BN / 2) + jp * 32 + 4 * g4;
+                    const bool nok = n < p.N;                   // N % 32 == 0: a block is inside or outside as a whole
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                    if (p.bias && nok) {
+                        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 16);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (p.act == 1) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                        else if (p.act == 2) v[r] = gelu_tanh_f(v[r]);
+                        else if (p.act == 3) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                        v[r] = to_f32(from_f32<T>(v[r]));       // the value the 16-bit path would have stored (same input to the quantiser)
+                        amax = fmaxf(amax, fabsf(v[r]));
+                    }
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    const int e = mx_scale_e8m0(amax);
+                    const float inv = mx_inv_scale(e);
+                    if (live && nok) {
+                        char* dst = (char*)p.C8 + (long)m * p.ldc8 + p.c8_col + n;
+                        *(uint32_t*)dst = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+                        *(uint32_t*)(dst + 16) = mx_pack4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+                        if (g4 == 0) { const int kb = (p.c8_col + n) >> 5; ((uint8_t*)p.SC)[((long)(kb >> 2) * p.sc_ld + m) * 4 + (kb & 3)] = (uint8_t)e; }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
+    const T* __restrict__ Rp = (const T*)p.R;
+    T* __restrict__ Cp = (T*)p.C;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
+        if (BN != 128 || !p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const bool full = (n + 3) < p.N;
+                if (full) {
+                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                    } else if (p.act == 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                    }
+                    if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                    if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
+                    if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                    if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
+                                  v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
+                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        float x = v[r];
+                        if (p.bias) x += p.bias[n + r];
+                        if (rv) x += rv[n + r];
+                        if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+                        else if (p.act == 2) x = gelu_tanh_f(x);
+                        else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+                        if (gt) x *= gt[n + r];
+                        if (p.oscale != 0.f) x *= p.oscale;
+                        if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+                        if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
+                        if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
+                        if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
+                    }
+                }
+            }
+        } else if (BN == 128) {
+            // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int na = n0 + wn * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
+                const int ng = na + 32;                                // GEMM column of 'g'
+                if (ng >= p.N) continue;
+                const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
+                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                constexpr int JG = (BN == 128) ? 2 : 0;
+                float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
+                if (p.bias) {
+                    const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+                }
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = a[r] * (p.geglu == 2 ? gelu_tanh_f(g[r]) : gelu_erf_f(g[r]));
+                if (Cp) *(uint2*)(Cp + (long)m * p.ldc + no) = pack4<T>(v[0], v[1], v[2], v[3]);
+                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
 // BM x BN workgroup tile, 4 waves as 2x2, each wave (BM/2) x (BN/2) = MI x NJ MFMA tiles of 16x16.
 // 128x128 / 128x160 for large problems; 64x64 for short-K problems whose 128-wide tiling would leave most CUs
 // idle (they are latency-bound: 4-5x more, smaller workgroups hide the HBM/L2 latency with thread-level parallelism).
@@ -316,142 +458,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
         __syncthreads();
     }
 
-    // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
-    if (S > 1) {
-        float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + l15;
-            if (m >= p.M) continue;
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
-                if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
-            }
-        }
-        return;
-    }
-    // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
-    if (p.C8) {
-        if constexpr ((BN / 2) % 32 == 0) {
-#pragma unroll
-            for (int i = 0; i < MI; ++i) {
-                const int m = m0 + wm * (BM / WM) + i * 16 + l15;
-                const bool live = m < p.M;                      // no early exit: every lane takes part in the exchanges
-#pragma unroll
-                for (int jp = 0; jp < NJ / 2; ++jp) {
-                    const int n = n0 + wn * (BN / 2) + jp * 32 + 4 * g4;
-                    const bool nok = n < p.N;                   // N % 32 == 0: a block is inside or outside as a whole
-                    float v[8];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
-                    if (p.bias && nok) {
-                        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 16);
-                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
-                    }
-                    float amax = 0.f;
-#pragma unroll
-                    for (int r = 0; r < 8; ++r) {
-                        if (p.act == 1) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
-                        else if (p.act == 2) v[r] = gelu_tanh_f(v[r]);
-                        else if (p.act == 3) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
-                        v[r] = to_f32(from_f32<T>(v[r]));       // the value the 16-bit path would have stored (same input to the quantiser)
-                        amax = fmaxf(amax, fabsf(v[r]));
-                    }
-                    amax = fmaxf(amax, __shfl_xor(amax, 16));
-                    amax = fmaxf(amax, __shfl_xor(amax, 32));
-                    const int e = mx_scale_e8m0(amax);
-                    const float inv = mx_inv_scale(e);
-                    if (live && nok) {
-                        char* dst = (char*)p.C8 + (long)m * p.ldc8 + p.c8_col + n;
-                        *(uint32_t*)dst = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
-                        *(uint32_t*)(dst + 16) = mx_pack4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
-                        if (g4 == 0) { const int kb = (p.c8_col + n) >> 5; ((uint8_t*)p.SC)[((long)(kb >> 2) * p.sc_ld + m) * 4 + (kb & 3)] = (uint8_t)e; }
-                    }
-                }
-            }
-        }
-        return;
-    }
-    // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
-    const T* __restrict__ Rp = (const T*)p.R;
-    T* __restrict__ Cp = (T*)p.C;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-        const int m = m0 + wm * (BM / WM) + i * 16 + l15;
-        if (m >= p.M) continue;
-        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
-        const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
-        if (BN != 128 || !p.geglu) {
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
-                if (n >= p.N) continue;
-                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                const bool full = (n + 3) < p.N;
-                if (full) {
-                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    if (p.act == 1) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
-                    } else if (p.act == 2) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
-                    } else if (p.act == 3) {
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
-                    }
-                    if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
-                    if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                    if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
-                    if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
-                                  v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
-                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
-                    if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        float x = v[r];
-                        if (p.bias) x += p.bias[n + r];
-                        if (rv) x += rv[n + r];
-                        if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
-                        else if (p.act == 2) x = gelu_tanh_f(x);
-                        else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
-                        if (gt) x *= gt[n + r];
-                        if (p.oscale != 0.f) x *= p.oscale;
-                        if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
-                        if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
-                        if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
-                        if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
-                    }
-                }
-            }
-        } else if (BN == 128) {
-            // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
-#pragma unroll
-            for (int j = 0; j < 2; ++j) {
-                const int na = n0 + wn * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
-                const int ng = na + 32;                                // GEMM column of 'g'
-                if (ng >= p.N) continue;
-                const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
-                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                constexpr int JG = (BN == 128) ? 2 : 0;
-                float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
-                if (p.bias) {
-                    const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
-                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
-                    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
-                }
-                float v[4];
-#pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = a[r] * (p.geglu == 2 ? gelu_tanh_f(g[r]) : gelu_erf_f(g[r]));
-                if (Cp) *(uint2*)(Cp + (long)m * p.ldc + no) = pack4<T>(v[0], v[1], v[2], v[3]);
-                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
-            }
-        }
-    }
+    gemm_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, m0, n0, wm, wn, l15, g4, split, S);
 }
+
+#include "gemm_pp.inc"
 
 template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
@@ -525,27 +535,36 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 // tile selection: {BM, BN}
 struct TileSel { int bm, bn; };
-static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, bool long_k_plain = false) {
+static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, bool allow_pp = true) {
     static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;      // experiment switch: BM*1000+BN
     if (force) return {force / 1000, force % 1000};
     if (!geglu && N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
     if (!geglu && N <= 64 && splitk <= 1 && (long)((M + 127) / 128) >= 400) return {128, 64};
-    // Large-M problems: 256-row tiles on 8 waves (one workgroup per CU) move 25-35 % fewer L2->LDS bytes per flop, which is
-    // what bounds the 128-row kernel there.  Needs about a full round of 256 workgroups and a well-filled last round.
-    // Measured: +8..17 % on isolated large GEMMs / convs (operands L2/MALL-resident), but -2 % (Flux forward) to -6 % (VAE decode)
-    // in the real launch sequences, where one workgroup per CU overlaps kernel tails worse: opt-in (LDX_TILE256=1).
-    // ... except very long K (>= 8192) plain 16-bit GEMMs, where the 256-row tile wins in the launch sequence too since the T14
-    // staging schedule (Flux single-block linear2, 4352 x 3072 x 15360: forward 98.2 -> 94.6 ms, same box); the MX kernel still
-    // loses with it on that shape (67.4 -> 69.7 ms)
-    static const bool env256 = getenv("LDX_TILE256") != nullptr;
-    const bool use256 = env256 || long_k_plain;
-    if (use256 && splitk <= 1 && M >= 2048 && !(geglu && K < 1024)) {
-        const long mt = (M + 255) / 256;
-        auto eff = [&](int bn) { const long t = mt * ((N + bn - 1) / bn); return t < 230 ? 0.0 : (double)t / (double)(((t + 255) / 256) * 256); };
-        const double e128 = eff(128), e160 = geglu ? 0.0 : eff(160);
-        const double waste160 = (double)(((N + 159) / 160) * 160 - N) / (double)N;
-        const bool use160 = e160 > 0.0 && waste160 <= 0.05 && e160 >= e128 - 0.08;
-        if ((use160 ? e160 : e128) >= 0.78) return {256, use160 ? 160 : 128};
+    // Large problems: the 256-row ping-pong kernel (gemm_pp.inc; one 8-wave workgroup per CU, LDS-DMA ring) when a simple cost model
+    // says so.  Isolated rates on MI355X (profiles/kprobe.py pp, bf16): 256 x 256 tiles 1.2-1.4 PFLOP/s, 256 x 160 0.95-1.2, 256 x 128
+    // ~1.0 on long K, against 0.72-0.96 for the register-staged 128-row kernel; short-K problems (a handful of K-tiles) are bound by
+    // per-launch fixed costs and the output write instead and gain nothing, and N = 128 (VAE 1024^2 level) loses.
+    // cost = rounds x slots x tile area / rate; LDX_PP: 0 off, 1 model (default), 2 whenever a candidate fills >= 3/4 of the CUs.
+    static const int pp_policy = getenv("LDX_PP") ? atoi(getenv("LDX_PP")) : 1;
+    static const int pp_mink = getenv("LDX_PP_MINK") ? atoi(getenv("LDX_PP_MINK")) : 1024;
+    if (allow_pp && pp_policy && M >= 1024 && N >= 256 && K >= pp_mink && !(geglu && K < 1024)) {
+        const long S = splitk > 1 ? splitk : 1, mt = (M + 255) / 256;
+        double best = 1e30; int best_bn = 0;
+        const int cand[3] = {256, 160, 128};
+        const double rate[3] = {1.35, 1.15, 0.92};
+        for (int c = 0; c < 3; ++c) {
+            if (geglu && cand[c] != 128) continue;
+            const long t = mt * ((N + cand[c] - 1) / cand[c]) * S;
+            if (t < 192) continue;                                   // would leave a quarter of the CUs idle
+            const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
+            if (cost < best) { best = cost; best_bn = cand[c]; }
+        }
+        if (best_bn) {
+            const int bo = geglu ? 128 : ((N % 160 == 0 && N % 128 != 0) ? 160 : 128);
+            const long to = (long)((M + 127) / 128) * ((N + bo - 1) / bo) * S;
+            const double cost_old = (double)((to + 511) / 512) * 512.0 * 128.0 * bo / 0.84;
+            if (pp_policy >= 2 || best < 0.95 * cost_old) return {256, best_bn};
+        }
     }
     if (geglu) return {128, 128};
     int bn = (N % 160 == 0 && N % 128 != 0) ? 160 : 128;
@@ -573,19 +592,28 @@ static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
+template <typename T, int MODE, int BN>
+static void launch_gemm_pp_inst(const GemmArgs& a, int S, hipStream_t s) {
+    const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * S;
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)gemm_pp_kernel<T, MODE, BN>, PP_LDS);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, MODE, BN>), dim3(tiles), dim3(512), PP_LDS, s, a);
+}
+
 template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
-        const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S);
+        const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S, false);      // no MX ping-pong kernel yet (256 x 128 only when forced)
         if (t.bm == 256 && t.bn == 128) launch_gemm_inst<T, 0, 256, 128, 4, true>(a, S, s);      // opt-in (LDX_TILE256)
         else if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
         else if (t.bn == 160 && !a.C8) launch_gemm_inst<T, 0, 128, 160, 2, true>(a, S, s);
         else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
         return;
     }
-    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S, MODE == 0 && a.K >= 8192);
-    if (t.bm == 256 && t.bn == 160) launch_gemm_inst<T, MODE, 256, 160, 4>(a, S, s);
-    else if (t.bm == 256) launch_gemm_inst<T, MODE, 256, 128, 4>(a, S, s);
+    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
+    if (t.bm == 256 && t.bn == 256 && !a.geglu) launch_gemm_pp_inst<T, MODE, 256>(a, S, s);
+    else if (t.bm == 256 && t.bn == 160 && !a.geglu) launch_gemm_pp_inst<T, MODE, 160>(a, S, s);
+    else if (t.bm == 256) launch_gemm_pp_inst<T, MODE, 128>(a, S, s);
     else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
     else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);
     else if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);

@@ -88,3 +88,9 @@ if __name__ == "__main__":
         for (M, N) in ((32768, 320), (8192, 640), (2048, 1280)):
             for K in (64, 128, 320, 640, 1280, 2560):
                 gemm(M, N, K)
+    if what == "pp":       # shapes for the 256-row ping-pong tiles (run with LDX_GEMM_TILE unset / =256128 / 256160 / 256256)
+        for s in ((32768, 320, 320), (32768, 960, 320), (32768, 320, 1280), (32768, 2560, 320), (8192, 640, 640), (8192, 640, 2560),
+                  (4096, 3072, 3072), (4352, 9216, 3072), (4352, 3072, 15360), (4096, 12288, 3072), (4096, 4096, 4096), (8192, 8192, 8192)):
+            gemm(*s)
+        conv(); conv(Cin=640, Cout=320); conv(Cin=960, Cout=320); conv(H=64, Cin=640, Cout=640); conv(H=64, Cin=1280, Cout=640)
+        conv(B=1, H=512, Cin=256, Cout=256); conv(B=1, H=1024, Cin=128, Cout=128)
