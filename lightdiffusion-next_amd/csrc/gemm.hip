@@ -665,11 +665,42 @@ static void launch_gemm2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) 
     set_dyn_lds(once, (const void*)gemm2_kernel<T, 128, 128, F8>, (int)lds);
     hipLaunchKernelGGL((gemm2_kernel<T, 128, 128, F8>), dim3(ta + tb), dim3(256), lds, s, a, b, ta);
 }
-// both plain mode, no split-K, no GEGLU, same operand kind (16-bit or MX); 128x128 tiles
+template <typename T, int BN>
+static void launch_gemm_pp2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
+    const int ta = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN), tb = ((b.M + 255) / 256) * ((b.N + BN - 1) / BN);
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)gemm_pp2_kernel<T, BN>, PP_LDS);
+    hipLaunchKernelGGL((gemm_pp2_kernel<T, BN>), dim3(ta + tb), dim3(512), PP_LDS, s, a, b, ta);
+}
+// 256-row ping-pong tiles for a two-problem launch: same cost model as gemm_tile over the combined tile count; 0 = keep 128 x 128
+static int gemm2_pp_bn(const GemmArgs& a, const GemmArgs& b) {
+    static const int pp_policy = getenv("LDX_PP") ? atoi(getenv("LDX_PP")) : 1;
+    static const int pp_mink = getenv("LDX_PP_MINK") ? atoi(getenv("LDX_PP_MINK")) : 1024;
+    if (!pp_policy || a.f8 || b.f8 || a.K < pp_mink || b.K < pp_mink || a.N < 256 || b.N < 256 || a.M + b.M < 1024) return 0;
+    double best = 1e30; int best_bn = 0;
+    const int cand[3] = {256, 160, 128};
+    const double rate[3] = {1.35, 1.15, 0.92};
+    for (int c = 0; c < 3; ++c) {
+        const long t = (long)((a.M + 255) / 256) * ((a.N + cand[c] - 1) / cand[c]) + (long)((b.M + 255) / 256) * ((b.N + cand[c] - 1) / cand[c]);
+        if (t < 192) continue;
+        const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
+        if (cost < best) { best = cost; best_bn = cand[c]; }
+    }
+    if (!best_bn) return 0;
+    const long to = (long)((a.M + 127) / 128) * ((a.N + 127) / 128) + (long)((b.M + 127) / 128) * ((b.N + 127) / 128);
+    const double cost_old = (double)((to + 511) / 512) * 512.0 * 128.0 * 128.0 / 0.84;
+    return (pp_policy >= 2 || best < 0.95 * cost_old) ? best_bn : 0;
+}
+// both plain mode, no split-K, no GEGLU, same operand kind (16-bit or MX); 128x128 tiles, or 256-row ping-pong tiles (16-bit)
 void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) { launch_gemm(b, dt, s); return; }
     if (b.M <= 0 || b.N <= 0) { launch_gemm(a, dt, s); return; }
     GemmArgs x = a, y = b; x.splitk = y.splitk = 1;
+    if (const int bn = gemm2_pp_bn(x, y)) {
+        if (dt == DT_BF16) { if (bn == 256) launch_gemm_pp2_t<__bf16, 256>(x, y, s); else if (bn == 160) launch_gemm_pp2_t<__bf16, 160>(x, y, s); else launch_gemm_pp2_t<__bf16, 128>(x, y, s); }
+        else { if (bn == 256) launch_gemm_pp2_t<_Float16, 256>(x, y, s); else if (bn == 160) launch_gemm_pp2_t<_Float16, 160>(x, y, s); else launch_gemm_pp2_t<_Float16, 128>(x, y, s); }
+        return;
+    }
     if (dt == DT_BF16) { if (a.f8) launch_gemm2_t<__bf16, true>(x, y, s); else launch_gemm2_t<__bf16, false>(x, y, s); }
     else { if (a.f8) launch_gemm2_t<_Float16, true>(x, y, s); else launch_gemm2_t<_Float16, false>(x, y, s); }
 }

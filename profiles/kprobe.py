@@ -27,6 +27,25 @@ def timeit(fn, reps=20, warm=3):
     return e0.elapsed_time(e1) / reps
 
 
+def timeit_graph(fn, reps=50, warm=3):
+    """Host launch cost (ctypes from Python: >= 10 us per call) out of the picture: capture `reps` launches in a hipGraph, replay."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay(); torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(3):
+        g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / (3 * reps)
+
+
 def attn(B=2, H=8, N=16384, M=None, D=40, reps=10):
     M = M or N
     C_ = H * D
@@ -94,3 +113,17 @@ if __name__ == "__main__":
             gemm(*s)
         conv(); conv(Cin=640, Cout=320); conv(Cin=960, Cout=320); conv(H=64, Cin=640, Cout=640); conv(H=64, Cin=1280, Cout=640)
         conv(B=1, H=512, Cin=256, Cout=256); conv(B=1, H=1024, Cin=128, Cout=128)
+    if what == "cold":     # hot vs cold operands: rotate over enough distinct buffers to exceed the 256 MiB Infinity Cache
+        def gemm_cold(M, N, K, nbuf_a, nbuf_w, reps=200):
+            As = [torch.randn(M, K, device="cuda").bfloat16() for _ in range(nbuf_a)]
+            Ws = [torch.randn(N, K, device="cuda").bfloat16() for _ in range(nbuf_w)]
+            Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            i = [0]
+            def fn():
+                a = As[i[0] % nbuf_a]; w = Ws[i[0] % nbuf_w]; i[0] += 1
+                L.ldx_op_gemm(p(a), K, p(w), M, N, K, None, None, 0, 1, 0, None, 0, p(Cc), N, None, 0, 0, st())
+            ms = timeit_graph(fn, reps)
+            print(f"gemm {M}x{N}x{K} A x{nbuf_a} W x{nbuf_w}: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+        for (M, N, K) in ((2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320), (512, 1280, 1280)):
+            wn = max(1, int(400e6 / (N * K * 2))); an = max(1, int(400e6 / (M * K * 2)))
+            gemm_cold(M, N, K, 1, 1); gemm_cold(M, N, K, 1, wn); gemm_cold(M, N, K, an, 1); gemm_cold(M, N, K, an, wn)
