@@ -171,6 +171,10 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
  * (negative counts from the end, e.g. -2 = clip-skip 2; Clip.py:218-236).  Causal mask, no padding mask. */
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
+/* Textual-inversion vectors (SDClipModel.set_up_textual_embeddings, src/SD15/SDClip.py:213-267): rows_host [n][hidden] fp32
+ * (HOST pointer) become token ids vocab_size .. vocab_size + n - 1 for the following ldx_clip_encode calls; n = 0 removes
+ * them.  Synchronous.  The reference rebuilds its nn.Embedding per forward; the engine keeps one side table instead. */
+int ldx_clip_set_extra_embeddings(ldx_engine* e, const float* rows_host, int n);
 
 /* ---- ESRGAN upscaler --------------------------------------------------------------------------- */
 /* Keys: RRDBNet's own module names ("model.0.weight", "model.1.sub.0.RDB1.conv1.0.weight", ..., "model.1.sub.<nb>.weight",

@@ -5,8 +5,9 @@ All of this is load-time host work (the result is handed to ldx_load_tensor / UN
 Reference: src/FileManaging/Loader.py:11-111 (CheckpointLoaderSimple), src/Model/LoRas.py:15-155 (key maps, load_lora),
 src/Model/ModelPatcher.py:621-650 (calculate_weight), src/NeuralNetwork/unet.py:12-185 (diffusers <-> ldm key map).
 """
+import os
 import re
-from typing import Dict, Tuple
+from typing import Dict, Optional, Sequence, Tuple, Union
 
 import torch
 
@@ -188,3 +189,75 @@ def merge_lora(weights: Dict[str, torch.Tensor], lora: Dict[str, torch.Tensor], 
         out[target] = (w.float() + delta.reshape(w.shape)).to(w.dtype) if w.dtype != torch.float32 else w + delta.reshape(w.shape)
         n += 1
     return out, n
+
+
+# ---------------------------------------------------------------------------------------------------
+# Textual-inversion embedding files (src/SD15/SDToken.py:108-206)
+_EMBED_EXT = (".safetensors", ".pt", ".bin")
+
+
+def _embedding_search_dirs(directories) -> list:
+    """Every directory under the given ones, symlinks followed (expand_directory_list, SDToken.py:108-122)."""
+    out = set()
+    for d in directories:
+        out.add(d)
+        for root, _sub, _files in os.walk(d, followlinks=True):
+            out.add(root)
+    return list(out)
+
+
+def load_embed(embedding_name: str, embedding_directory: Union[str, Sequence[str]], embedding_size: int,
+               embed_key: Optional[str] = None) -> Optional[torch.Tensor]:
+    """The tensor the reference's load_embed returns for "embedding:<name>" (SDToken.py:125-206), or None.
+
+    File lookup: <dir>/<name> for every directory of the tree, else the same path with .safetensors / .pt / .bin appended;
+    a name that escapes its directory ("../x") is refused.  Layouts, in the reference's order of precedence:
+      {"string_to_param": {tok: T}}   -> first T (A1111 .pt)
+      [ {k: T, ...}, ... ]            -> rows of every T whose last dim == embedding_size, concatenated
+      {embed_key: T, ...}             -> T            (e.g. "clip_l" of an SDXL-style file)
+      {k: T, ...}                     -> first T      (plain safetensors: "emb_params")
+    A file that fails to load is skipped (None), as the reference does after logging."""
+    dirs = [embedding_directory] if isinstance(embedding_directory, str) else list(embedding_directory)
+    found = None
+    for d in _embedding_search_dirs(dirs):
+        base, path = os.path.abspath(d), os.path.abspath(os.path.join(d, embedding_name))
+        try:
+            if os.path.commonpath((base, path)) != base:
+                continue
+        except ValueError:
+            continue
+        if os.path.isfile(path):
+            found = path
+        else:
+            found = next((path + e for e in _EMBED_EXT if os.path.isfile(path + e)), None)
+        if found is not None:
+            break
+    if found is None:
+        return None
+    try:
+        if found.lower().endswith(".safetensors"):
+            import safetensors.torch
+            data = safetensors.torch.load_file(found, device="cpu")
+        else:
+            data = torch.load(found, weights_only=True, map_location="cpu")
+    except Exception:
+        return None
+    if isinstance(data, dict) and "string_to_param" in data:
+        return next(iter(data["string_to_param"].values()))
+    if isinstance(data, list):
+        rows = [t.reshape(-1, t.shape[-1]) for entry in data for t in entry.values() if t.shape[-1] == embedding_size]
+        return torch.cat(rows, dim=0)
+    if embed_key is not None and embed_key in data:
+        return data[embed_key]
+    return next(iter(data.values()))
+
+
+class EmbeddingDirectory:
+    """`embeddings=` argument of prompt.tokenize_with_weights backed by files: .get(name) = load_embed(name, ...), like
+    SDTokenizer._try_get_embedding (SDToken.py:264-290; the retry without trailing commas is done by the caller)."""
+
+    def __init__(self, directories, embedding_size: int = 768, embed_key: str = "clip_l"):
+        self.directories, self.embedding_size, self.embed_key = directories, embedding_size, embed_key
+
+    def get(self, name: str):
+        return load_embed(name, self.directories, self.embedding_size, self.embed_key)

@@ -104,6 +104,12 @@ int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_l
     return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_clip_set_extra_embeddings(ldx_engine* e, const float* rows_host, int n) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->set_clip_extra(rows_host, n);
+    GUARD_END
+}
 int ldx_esrgan_create(const ldx_esrgan_config* cfg, int device, ldx_engine** out) {
     GUARD_BEGIN
     if (!cfg || !out) { set_error("ldx_esrgan_create: null argument"); return LDX_EINVAL; }

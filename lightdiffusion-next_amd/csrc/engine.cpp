@@ -822,7 +822,8 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_VAEPREP: launch_vae_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, vae_pq, vae_pq ? vae_pq + o.i1 * o.i1 : nullptr, dt, ls); break;
             case OP_SOFTMAX: launch_softmax_rows(o.p1, o.i0, o.i1, o.i2, o.f0, dt, ls); break;
             case OP_CLAMP: launch_clamp01((const float*)o.p0, b_out, (size_t)o.i0, ls); break;
-            case OP_EMBED: launch_clip_embed(b_ids, kind == KIND_T5 ? t5_tok : clip_tok, kind == KIND_T5 ? nullptr : clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
+            case OP_EMBED: launch_clip_embed(b_ids, kind == KIND_T5 ? t5_tok : clip_tok, kind == KIND_T5 ? nullptr : clip_pos, o.p1, o.i0, o.i1, o.i2, o.i3,
+                                              kind == KIND_T5 ? nullptr : clip_extra, kind == KIND_T5 ? 0 : clip_extra_n, dt, ls); break;
             case OP_CVT_OUT: if ((o.i3 ? b_out2 : b_out) != nullptr) launch_t_to_f32(o.p0, o.i3 ? b_out2 : b_out, (size_t)o.i0, dt, ls); break;
             case OP_PIXPREP: launch_pixels_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, o.f0, o.f1, dt, ls); break;
             case OP_COPY_OUT: HIP_OK(hipMemcpyAsync(b_out, o.p0, (size_t)o.cvt_n, hipMemcpyDeviceToDevice, ls)); break;

@@ -105,6 +105,7 @@ public:
     int plan_vae_encode(int B, int H, int W);
     int run_vae_encode(const float* px, int B, int H, int W, float* moments, hipStream_t st);
     int run_clip(const int* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, hipStream_t st);
+    int set_clip_extra(const float* rows_host, int n);
     ~Engine();
     int validate() const;
     int load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
@@ -163,6 +164,7 @@ private:
     float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
     // CLIP
     std::vector<ClipLayerW> clip_layers; NormW clip_final_ln; float* clip_tok = nullptr; float* clip_pos = nullptr;
+    float* clip_extra = nullptr; int clip_extra_n = 0, clip_extra_cap = 0;     // textual-inversion rows for ids >= vocab_size
     int clip_inter_planned = -100;
     LinearW te0, te2, conv_in, conv_out, emb_all;
     NormW out_gn;

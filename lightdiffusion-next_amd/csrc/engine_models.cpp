@@ -417,6 +417,26 @@ int Engine::plan_clip(int B, int T, int inter) {
     return LDX_OK;
 }
 
+// Textual-inversion vectors for the next ldx_clip_encode calls: the reference extends the token table by one row per vector
+// and gives those rows the ids vocab_size, vocab_size + 1, ... (SDClipModel.set_up_textual_embeddings, SD15/SDClip.py:213-267).
+// Host rows [n][hidden] fp32; n = 0 removes them.  Synchronous (cudaMemcpy); the buffer grows, never shrinks.
+int Engine::set_clip_extra(const float* rows_host, int n) {
+    if (!finalized || kind != KIND_CLIP) { set_error("ldx_clip_set_extra_embeddings: not a finalized CLIP engine"); return LDX_ESTATE; }
+    if (n < 0 || (n > 0 && !rows_host)) { set_error("ldx_clip_set_extra_embeddings: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    HIP_OK(hipDeviceSynchronize());                    // a previous encode may still read the old rows
+    const size_t E = (size_t)ccfg.hidden_size;
+    if (n > clip_extra_cap) {
+        float* p = nullptr;
+        HIP_OK(hipMalloc((void**)&p, (size_t)n * E * sizeof(float)));
+        dev_allocs.push_back(p);                       // the old (smaller) buffer stays owned by the engine until it is destroyed
+        clip_extra = p; clip_extra_cap = n;
+    }
+    if (n > 0) HIP_OK(hipMemcpy(clip_extra, rows_host, (size_t)n * E * sizeof(float), hipMemcpyHostToDevice));
+    clip_extra_n = n;
+    return LDX_OK;
+}
+
 int Engine::run_clip(const int* ids, int B, int T, int inter_layer, float* out_last, float* out_inter, hipStream_t st) {
     if (!finalized || kind != KIND_CLIP) { set_error("ldx_clip_encode: not a finalized CLIP engine"); return LDX_ESTATE; }
     if (!ids || !out_last || B <= 0 || T <= 0 || T > ccfg.max_positions) { set_error("ldx_clip_encode: bad argument"); return LDX_EINVAL; }

@@ -164,7 +164,8 @@ void launch_clamp01(const float* in, float* out, size_t n, hipStream_t s);
 // row softmax in place on a 16-bit [rows][ld] matrix: p = softmax(x * scale) (VAE AttnBlock, D = 512 single head)
 void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType dt, hipStream_t s);
 // CLIP embeddings (clip/Clip.py:254-294): x[b][t][:] = tok[id[b][t]][:] + pos[t][:]  (fp32 tables -> 16-bit)
-void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int T, int C, int vocab, DType dt, hipStream_t s);
+// ids in [vocab, vocab + n_extra) read row id - vocab of `extra` (textual-inversion vectors, SD15/SDClip.py:213-267)
+void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int T, int C, int vocab, const float* extra, int n_extra, DType dt, hipStream_t s);
 
 // First-block cache helpers on the joint token buffer X [B][L][C] (16-bit; rows [0, Lt) text, [Lt, L) image per batch).
 // fb_diff: sums[0] = sum |(X - S0) - F| , sums[1] = sum |F| over the image rows (deterministic two-stage reduction through

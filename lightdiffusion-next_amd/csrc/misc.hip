@@ -231,24 +231,27 @@ void launch_softmax_rows(void* X, int rows, int cols, int ld, float scale, DType
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const float* tok, const float* pos, T* out, int B, int Tn, int C, int vocab) {
+__global__ __launch_bounds__(256) void clip_embed_kernel(const int* ids, const float* tok, const float* pos, T* out, int B, int Tn, int C, int vocab,
+                                                          const float* extra, int n_extra) {
     const long total = (long)B * Tn * (C / 8);
     for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
         const int ch = (int)(idx % (C / 8));
         const long bt = idx / (C / 8);
         const int t = (int)(bt % Tn);
         int id = ids[bt];
-        id = max(0, min(id, vocab - 1));
+        id = max(0, min(id, vocab + n_extra - 1));
+        // ids >= vocab address the textual-inversion rows appended to the table for this call (SDClip.py:213-267)
+        const float* row = id < vocab ? tok + (long)id * C : extra + (long)(id - vocab) * C;
         float f[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) f[e] = tok[(long)id * C + ch * 8 + e] + (pos ? pos[(long)t * C + ch * 8 + e] : 0.f);
+        for (int e = 0; e < 8; ++e) f[e] = row[ch * 8 + e] + (pos ? pos[(long)t * C + ch * 8 + e] : 0.f);
         *(uint4*)(out + bt * C + ch * 8) = pack8<T>(f);
     }
 }
-void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int Tn, int C, int vocab, DType dt, hipStream_t s) {
+void launch_clip_embed(const int* ids, const float* tok, const float* pos, void* out, int B, int Tn, int C, int vocab, const float* extra, int n_extra, DType dt, hipStream_t s) {
     const size_t total = (size_t)B * Tn * (C / 8);
-    if (dt == DT_BF16) hipLaunchKernelGGL((clip_embed_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (__bf16*)out, B, Tn, C, vocab);
-    else hipLaunchKernelGGL((clip_embed_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (_Float16*)out, B, Tn, C, vocab);
+    if (dt == DT_BF16) hipLaunchKernelGGL((clip_embed_kernel<__bf16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (__bf16*)out, B, Tn, C, vocab, extra, n_extra);
+    else hipLaunchKernelGGL((clip_embed_kernel<_Float16>), dim3(grid_for(total)), dim3(256), 0, s, ids, tok, pos, (_Float16*)out, B, Tn, C, vocab, extra, n_extra);
 }
 
 __global__ __launch_bounds__(256) void flux_temb_kernel(const float* t, float* out, int B, int dim, float factor) {

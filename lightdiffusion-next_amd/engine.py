@@ -7,6 +7,8 @@ Reference counterparts: BaseModel.__init__/load_model_weights/apply_model (src/M
 import ctypes as C
 import math
 
+import numbers
+
 import torch
 
 from . import lib
@@ -240,6 +242,7 @@ class CLIPTextEngine:
         _load_state_dict(self._lib, self._h, {k: v for k, v in state_dict.items() if "text_projection" not in k},
                          strip=("text_model.",))
         lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
+        self._tok_dtype = next(v.dtype for k, v in state_dict.items() if k.endswith("embeddings.token_embedding.weight"))
         tp = state_dict.get("text_projection.weight")
         self.text_projection = None if tp is None else tp.float().to(self.device)
 
@@ -258,8 +261,26 @@ class CLIPTextEngine:
             pooled = pooled @ self.text_projection.t()
         return last, inter, pooled
 
+    _extra_rows = 0
+
+    def _textual_embeddings(self, chunks, pad_token):
+        """SDClipModel.set_up_textual_embeddings (SDClip.py:213-267): a token that is a vector of the model's width becomes
+        the id vocab_size + k of an appended table row; a vector of another width is dropped and the chunk re-padded."""
+        e, nxt, rows, out = self.cfg.hidden_size, self.cfg.vocab_size, [], []
+        for chunk in chunks:
+            ids = []
+            for t in chunk:
+                if isinstance(t, numbers.Integral):
+                    ids.append(int(t))
+                elif t.shape[0] == e:
+                    rows.append(torch.as_tensor(t)); ids.append(nxt); nxt += 1
+            ids += [pad_token] * (len(chunk) - len(ids))
+            out.append(ids)
+        return out, rows
+
     def encode_token_weights(self, token_weight_pairs, layer_idx=-2, special_tokens=(49406, 49407, 49407)):
-        """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) for a list of 77-token (id, weight) chunks."""
+        """ClipTokenWeightEncoder.encode_token_weights (SDClip.py:36-97) for a list of 77-token (id, weight) chunks; an id
+        may be a textual-inversion vector (prompt.tokenize_with_weights with embeddings=...)."""
         to_encode, has_weights, max_len = [], False, 0
         for x in token_weight_pairs:
             toks = [a[0] for a in x]
@@ -270,6 +291,13 @@ class CLIPTextEngine:
         if has_weights or sections == 0:
             start, end, pad = special_tokens
             to_encode.append([start, end] + [pad] * (max_len - 2))           # gen_empty_tokens (SDClip.py:10-20)
+        to_encode, extra = self._textual_embeddings(to_encode, special_tokens[2])
+        if extra or self._extra_rows:
+            # the reference copies the vectors into a table of the stored weights' dtype (SDClip.py:249-258): same rounding here
+            rows = torch.stack(extra).to(self._tok_dtype).float().contiguous() if extra else None
+            lib.check(self._lib.ldx_clip_set_extra_embeddings(self._h, None if rows is None else C.c_void_p(rows.data_ptr()), len(extra)),
+                      "ldx_clip_set_extra_embeddings")
+            self._extra_rows = len(extra)
         last, inter, pooled = self.forward(torch.tensor(to_encode, dtype=torch.int64), intermediate_output=layer_idx)
         out = (inter if layer_idx is not None else last).float().cpu()
         output = []

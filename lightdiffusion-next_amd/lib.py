@@ -78,6 +78,7 @@ _SIGS = {
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldx_clip_set_extra_embeddings": (_i, [_vp, _vp, _i]),
     "ldx_flux_fbcache": (_i, [_vp, _f]),
     "ldx_flux_set_fp8": (_i, [_vp, _i]),
     "ldx_flux_fbcache_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),

@@ -660,11 +660,32 @@ def vae_sample_moments(moments):
 
 # ---------------------------------------------------------------------------------------------------
 # CLIP text encoder  (src/clip/CLIPTextModel.py:51-107, src/clip/Clip.py:14-294, src/SD15/SDClip.py:36-97)
-def clip_forward(sd, cfg, tokens, intermediate_output=None, final_layer_norm_intermediate=True):
-    """CLIPTextModel_.forward: returns (x after final LN, intermediate (final-LN'd) or None, pooled)."""
+def clip_textual_embeddings(cfg, chunks, pad_token):
+    """SDClipModel.set_up_textual_embeddings (src/SD15/SDClip.py:213-267): vector tokens of the model's width are appended to
+    the token table and addressed as ids vocab_size, vocab_size + 1, ...; vectors of another width are dropped and the chunk
+    is re-padded with the pad token.  Returns (integer chunks, [extra rows])."""
+    nxt, rows, out = cfg.vocab_size, [], []
+    for chunk in chunks:
+        ids = []
+        for t in chunk:
+            if isinstance(t, int) or (hasattr(t, "ndim") and t.ndim == 0):
+                ids.append(int(t))
+            elif t.shape[0] == cfg.hidden_size:
+                rows.append(torch.as_tensor(t).float()); ids.append(nxt); nxt += 1
+        out.append(ids + [pad_token] * (len(chunk) - len(ids)))
+    return out, rows
+
+
+def clip_forward(sd, cfg, tokens, intermediate_output=None, final_layer_norm_intermediate=True, extra_rows=()):
+    """CLIPTextModel_.forward: returns (x after final LN, intermediate (final-LN'd) or None, pooled).  extra_rows: rows
+    appended to the token-embedding table for this call (textual inversion)."""
     w = W(sd)
     e, heads = cfg.hidden_size, cfg.num_heads
-    x = F.embedding(tokens, w("embeddings.token_embedding.weight")) + w("embeddings.position_embedding.weight")[: tokens.shape[1]]
+    table = w("embeddings.token_embedding.weight")
+    if len(extra_rows):      # the reference's new nn.Embedding has the stored table's dtype (fp16 checkpoints round the vectors)
+        stored = sd["embeddings.token_embedding.weight"].dtype
+        table = torch.cat([table, torch.stack(list(extra_rows)).to(stored).to(table.dtype)], dim=0)
+    x = F.embedding(tokens, table) + w("embeddings.position_embedding.weight")[: tokens.shape[1]]
     mask = torch.empty(x.shape[1], x.shape[1], dtype=x.dtype).fill_(float("-inf")).triu_(1)     # causal (CLIPTextModel.py:83-91)
     if intermediate_output is not None and intermediate_output < 0:
         intermediate_output = cfg.num_layers + intermediate_output                            # Clip.py:222-224
@@ -708,7 +729,8 @@ def clip_encode_token_weights(sd, cfg, token_weight_pairs, layer_idx=-2, special
     if has_weights or sections == 0:
         start, end, pad = special_tokens
         to_encode.append([start, end] + [pad] * (max_len - 2))
-    last, inter, pooled = clip_forward(sd, cfg, torch.LongTensor(to_encode), intermediate_output=layer_idx)
+    to_encode, extra = clip_textual_embeddings(cfg, to_encode, special_tokens[2])
+    last, inter, pooled = clip_forward(sd, cfg, torch.LongTensor(to_encode), intermediate_output=layer_idx, extra_rows=extra)
     out = (inter if layer_idx is not None else last).float()
     output = []
     for k in range(sections):

@@ -81,3 +81,30 @@ def test_clip_full_size_vs_oracle(ldx, ldx_lib, golden_dir):
     with torch.no_grad():
         rl, ri, _ = O.clip_forward(sd, cfg, ids, intermediate_output=-2)
     assert _rel(last, rl) <= 2.5e-2 and _rel(inter, ri) <= 2.5e-2
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_clip_textual_inversion_vs_reference_golden(ldx, ldx_lib, golden_dir, tmp_path, dt, tol):
+    """"embedding:name" words: files -> checkpoint.load_embed -> prompt.tokenize_with_weights -> vector tokens ->
+    ldx_clip_set_extra_embeddings + ldx_clip_encode, against the reference's SD1ClipModel on the same files."""
+    import json
+    from test_embed_cpu import write_embedding_files
+    g = np.load(os.path.join(golden_dir, "embed.npz"))
+    E = int(g["E"])
+    write_embedding_files(str(tmp_path), E, {k[2:]: torch.from_numpy(g[k]) for k in g.files if k.startswith("t_")})
+    vocab = json.loads(str(g["vocab"]))
+    cfg = ldx.CLIPConfig.tiny()
+    sd = ldx.weights.synth_state_dict(ldx.weights.clip_state_dict_spec(cfg), seed=777)
+    eng = ldx.CLIPTextEngine(cfg, sd, device=0, dtype=dt)
+    table = ldx.checkpoint.EmbeddingDirectory(str(tmp_path), embedding_size=E)
+    for i in list(range(len(g["prompts"]))) + [0]:                # prompt 0 again: fewer extra rows than the call before
+        chunks = ldx.prompt.tokenize_with_weights(str(g["prompts"][i]), lambda w: vocab[w], embeddings=table)
+        cond, pooled = eng.encode_token_weights(chunks, layer_idx=-2)
+        r = _rel(cond, g[f"cond_{i}"])
+        print(f"[{dt}] CLIP + textual inversion, prompt {i}: rel-L2 {r:.3e}")
+        assert cond.shape == g[f"cond_{i}"].shape and r <= tol and _rel(pooled, g[f"pooled_{i}"]) <= tol
+    # and a plain prompt afterwards must not see stale rows
+    gc = np.load(os.path.join(golden_dir, "clip.npz"))
+    pairs = [list(zip(gc["ids_0"][c].tolist(), gc["wts_0"][c].tolist())) for c in range(gc["ids_0"].shape[0])]
+    cond, _ = eng.encode_token_weights(pairs, layer_idx=-2)
+    assert _rel(cond, gc["cond_tiny_skip-2_0"]) <= tol
