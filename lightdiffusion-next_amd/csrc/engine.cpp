@@ -241,6 +241,35 @@ bool Engine::mk_norm(const std::string& pre, int C, NormW& out) {
     return out.g && out.b;
 }
 
+// Linear(LayerNorm(x)) with the norm folded in: y = rstd (x W'^T - mean c1) + c2 with W' = W .* gamma (per input column), c1[n] = sum_k W'[n][k]
+// (of the values as STORED in 16 bit: the epilogue subtracts exactly what the MFMA accumulated for a constant row) and c2 = W beta + b.
+bool Engine::mk_ln_folded(int N, int K, const std::function<float(size_t, size_t)>& W, const std::function<float(size_t)>& bias,
+                          const std::string& norm_pre, LinearW& out, float*& c1) {
+    const HostTensor* g = get(norm_pre + ".weight", {K});
+    const HostTensor* be = get(norm_pre + ".bias", {K});
+    if (!g || !be) return false;
+    std::vector<float> gam(K), bet(K);
+    for (int k = 0; k < K; ++k) { gam[k] = g->at(k); bet[k] = be->at(k); }
+    out.N = N; out.K = K;
+    out.w = upload16(N, K, [&](size_t r, size_t c) { return W(r, c) * gam[c]; });
+    std::vector<float> v1(N), v2(N);
+    const bool bf = dt == DT_BF16;
+    parallel_for(N, [&](size_t b, size_t e) {
+        for (size_t r = b; r < e; ++r) {
+            double s1 = 0.0, s2 = 0.0;
+            for (int k = 0; k < K; ++k) {
+                const float w = W(r, k), wg = w * gam[k];
+                s1 += bf ? bf16_to_float(float_to_bf16(wg)) : half_to_float(float_to_half(wg));
+                s2 += (double)w * bet[k];
+            }
+            v1[r] = (float)s1; v2[r] = (float)(s2 + (bias ? bias(r) : 0.f));
+        }
+    });
+    c1 = upload32(N, [&](size_t i) { return v1[i]; });
+    out.b = upload32(N, [&](size_t i) { return v2[i]; });
+    return out.w && c1 && out.b;
+}
+
 bool Engine::mk_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     r.Cin = Cin; r.Cout = Cout;
     if (!mk_norm(pre + ".in_layers.0", Cin, r.gn1)) return false;
@@ -295,14 +324,28 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         const HostTensor* k = get(bp + ".attn1.to_k.weight", {C, C});
         const HostTensor* v = get(bp + ".attn1.to_v.weight", {C, C});
         if (!q || !k || !v) return false;
-        b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.b = nullptr;
-        b.qkv.w = upload16((size_t)3 * C, C, [&](size_t r, size_t c) {
+        // LDX_LNFOLD=1: fold norm1/2/3 into the q|k|v / q / GEGLU projections (48 launches and the normalised copies of h less per step).
+        // Correct and tested, but measured neutral on MI355X (17.26 vs 17.14 ms per step): with every part of the fold switched off the
+        // consuming GEMM is still 16 us slower at level 0 when it follows the GEMM that wrote h than when a LayerNorm launch sits between
+        // them (50 -> 66 us; the statistics MFMAs, the LDS exchange and the epilogue add 8 more) - profiles/ubench/README.md.  Off by default.
+        static const bool fold_env = getenv("LDX_LNFOLD") != nullptr && atoi(getenv("LDX_LNFOLD")) != 0;
+        b.ln_fold = fold_env;
+        auto qkv_w = [&](size_t r, size_t c) {
             const HostTensor* s = r < (size_t)C ? q : (r < (size_t)2 * C ? k : v);
             return s->at((r % C) * C + c);
-        });
-        if (!b.qkv.w) return false;
+        };
+        const HostTensor* q2w = get(bp + ".attn2.to_q.weight", {C, C});
+        if (!q2w) return false;
+        if (b.ln_fold) {
+            if (!mk_ln_folded(3 * C, C, qkv_w, nullptr, bp + ".norm1", b.qkv, b.c1_qkv)) return false;
+            if (!mk_ln_folded(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c); }, nullptr, bp + ".norm2", b.q2, b.c1_q2)) return false;
+        } else {
+            b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.b = nullptr;
+            b.qkv.w = upload16((size_t)3 * C, C, qkv_w);
+            if (!b.qkv.w) return false;
+            if (!mk_linear(bp + ".attn2.to_q", C, C, false, b.q2)) return false;
+        }
         if (!mk_linear(bp + ".attn1.to_out.0", C, C, true, b.o1)) return false;
-        if (!mk_linear(bp + ".attn2.to_q", C, C, false, b.q2)) return false;
         const HostTensor* k2 = get(bp + ".attn2.to_k.weight", {C, ctx});
         const HostTensor* v2 = get(bp + ".attn2.to_v.weight", {C, ctx});
         if (!k2 || !v2) return false;
@@ -317,10 +360,15 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         const HostTensor* fb = get(bp + ".ff.net.0.proj.bias", {2 * inner});
         if (!fw || !fb) return false;
         auto src_row = [inner](size_t r) { const size_t slab = r / 64, within = r % 64; return within < 32 ? slab * 32 + within : inner + slab * 32 + (within - 32); };
-        b.ff1.N = 2 * inner; b.ff1.K = C;
-        b.ff1.w = upload16((size_t)2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); });
-        b.ff1.b = upload32((size_t)2 * inner, [&](size_t i) { return fb->at(src_row(i)); });
-        if (!b.ff1.w || !b.ff1.b) return false;
+        if (b.ln_fold) {
+            if (!mk_ln_folded(2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); }, [&](size_t i) { return fb->at(src_row(i)); },
+                              bp + ".norm3", b.ff1, b.c1_ff1)) return false;
+        } else {
+            b.ff1.N = 2 * inner; b.ff1.K = C;
+            b.ff1.w = upload16((size_t)2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); });
+            b.ff1.b = upload32((size_t)2 * inner, [&](size_t i) { return fb->at(src_row(i)); });
+            if (!b.ff1.w || !b.ff1.b) return false;
+        }
         if (!mk_linear(bp + ".ff.net.2", C, inner, true, b.ff2)) return false;
     }
     return true;
@@ -575,33 +623,47 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     Act h = new_act(M, C);
     op_gemm("xf.proj_in", t1, x.proj_in, h, Act{});
     release(t1);
+    // Folded LayerNorms (XfBlockW::ln_fold): the q|k|v / q / GEGLU GEMM reads h itself, accumulates each row's statistics from its own A
+    // fragments and normalises in its epilogue (GemmArgs::ln_c1): no LayerNorm launch, no normalised copy of h.  A split-K consumer keeps a
+    // plain (affine-free) LayerNorm launch in front of the folded weights.
+    const bool fold = x.depth > 0 && x.blocks[0].ln_fold;
+    Act n{};
+    auto ln_gemm = [&](const char* ln_name, const char* name, const NormW& ln, const LinearW& w, const float* c1, Act Cc, bool geglu) {
+        if (fold && gemm_choose_splitk(M, w.N, w.K, geglu) == 1) {
+            op_gemm(name, h, w, Cc, Act{}, geglu);
+            GemmArgs& g = ops.back().g;
+            g.ln_c1 = c1; g.ln_eps = 1e-5f;
+            return;
+        }
+        if (!n.valid) n = new_act(M, C);
+        NormW plain = ln;
+        if (fold) { plain.g = nullptr; plain.b = nullptr; }     // gamma / beta already live in the folded weights / bias
+        op_ln(ln_name, h, n, plain);
+        op_gemm(name, n, w, Cc, Act{}, geglu);
+    };
     for (int d = 0; d < x.depth; ++d) {
         const XfBlockW& b = x.blocks[d];
-        Act n = new_act(M, C);
-        op_ln("xf.ln1", h, n, b.ln1);
         Act qkv = new_act(M, 3 * C);
-        op_gemm("xf.qkv", n, b.qkv, qkv, Act{});
+        ln_gemm("xf.ln1", "xf.qkv", b.ln1, b.qkv, b.c1_qkv, qkv, false);
         Act a = new_act(M, C);
         const char* base = (const char*)ptr(qkv);
         op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
         release(qkv);
         op_gemm("xf.o1", a, b.o1, h, h);                       // x += attn1(norm1(x))   (in place)
-        op_ln("xf.ln2", h, n, b.ln2);
         Act q = new_act(M, C);
-        op_gemm("xf.q2", n, b.q2, q, Act{});
+        ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
         op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
         release(q);
         op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
         release(a);
-        op_ln("xf.ln3", h, n, b.ln3);
         Act f = new_act(M, 4 * C);
-        op_gemm("xf.ff1", n, b.ff1, f, Act{}, true);           // GEGLU
-        release(n);
+        ln_gemm("xf.ln3", "xf.ff1", b.ln3, b.ff1, b.c1_ff1, f, true);        // GEGLU
         op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
         release(f);
     }
+    if (n.valid) release(n);
     op_gemm("xf.proj_out", h, x.proj_out, OUT, X);             // + x_in
     release(h);
 }
@@ -758,6 +820,9 @@ void Engine::plan_stash() {
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
     s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den;
+    s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
+    s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
+    s.fb_B = fb_B; s.fb_L = fb_L; s.fb_Lt = fb_Lt; s.fb_C = fb_C; s.fb_a_end = fb_a_end; s.fb_b_end = fb_b_end;
     ops.clear(); arena = nullptr; arena_cap = 0; graph_exec = nullptr; graph_valid = false; warm = false; pB2 = ph = pw = pM = 0;
     plan_cache.push_back(std::move(s));
     if (plan_cache.size() > 4) {
@@ -775,6 +840,9 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc) {
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
         graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den;
+        fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
+        fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
+        fb_B = s.fb_B; fb_L = s.fb_L; fb_Lt = s.fb_Lt; fb_C = s.fb_C; fb_a_end = s.fb_a_end; fb_b_end = s.fb_b_end;
         pB2 = B2; ph = h; pw = w; pM = Mc;
         plan_cache.erase(plan_cache.begin() + i);
         return true;
@@ -804,7 +872,24 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             } break;
             case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
             case OP_SKINNY: launch_skinny(o.sk, dt, ls); break;
-            case OP_GEMM: launch_gemm(o.g, dt, ls); break;
+            case OP_GEMM: {
+                launch_gemm(o.g, dt, ls);
+                static const bool dbg_nan = getenv("LDX_DEBUG_NAN") != nullptr;          // debug: first GEMM whose 16-bit output holds a NaN / Inf
+                if (dbg_nan && o.g.C) {
+                    (void)hipStreamSynchronize(ls);
+                    const int Nout = o.g.geglu ? o.g.N / 2 : o.g.N;
+                    std::vector<uint16_t> hb((size_t)o.g.M * o.g.ldc);
+                    (void)hipMemcpy(hb.data(), o.g.C, ((size_t)(o.g.M - 1) * o.g.ldc + Nout) * 2, hipMemcpyDeviceToHost);
+                    long bad = 0, first = -1;
+                    for (long m = 0; m < o.g.M; ++m) for (int n = 0; n < Nout; ++n) {
+                        const uint16_t v = hb[(size_t)m * o.g.ldc + n];
+                        const bool b = dt == DT_BF16 ? ((v & 0x7f80) == 0x7f80) : ((v & 0x7c00) == 0x7c00);
+                        if (b) { ++bad; if (first < 0) first = m * (long)Nout + n; }
+                    }
+                    fprintf(stderr, "[nan] op %zu %-14s M%d N%d K%d sk%d ln%d rs%d: %ld bad%s\n", oi, o.name, o.g.M, o.g.N, o.g.K, o.g.splitk, o.g.ln_c1 ? 1 : 0,
+                            0, bad, bad ? (std::string(" first at row ") + std::to_string(first / Nout) + " col " + std::to_string(first % Nout)).c_str() : "");
+                }
+            } break;
             case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
             case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;

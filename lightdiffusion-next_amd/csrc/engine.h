@@ -29,7 +29,10 @@ struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0;
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; bool fused_skip = false; /* fused_skip: conv2 holds [W2 | Wskip], bias b2 + bskip */ int Cin = 0, Cout = 0; int emb_off = 0;
               float eps = 1e-5f; bool has_emb = true; };
-struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_off = 0; };
+struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_off = 0;
+    // ln_fold: norm1/2/3 are folded into qkv / q2 / ff1 (weights W .* gamma, bias W beta + b, c1_* = row sums of the stored weights):
+    // the GEMM reads the un-normalised rows and applies rstd * (acc - mean * c1) + bias in its epilogue (GemmArgs::ln_stat)
+    bool ln_fold = false; float *c1_qkv = nullptr, *c1_q2 = nullptr, *c1_ff1 = nullptr; };
 struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };
 struct BlockW { bool has_res = false, has_xf = false, has_down = false, has_up = false; ResW res; XfW xf; LinearW down, up; int skip_ch = 0; };
 
@@ -140,6 +143,8 @@ private:
     bool mk_linear(const std::string& pre, int N, int K, bool bias, LinearW& out, bool conv1x1 = false);
     bool mk_conv3(const std::string& pre, int Cout, int Cin, int CinPad, LinearW& out);
     bool mk_norm(const std::string& pre, int C, NormW& out);
+    bool mk_ln_folded(int N, int K, const std::function<float(size_t, size_t)>& W, const std::function<float(size_t)>& bias,
+                      const std::string& norm_pre, LinearW& out, float*& c1);
     bool mk_res(const std::string& pre, int Cin, int Cout, ResW& r);
     bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
 
@@ -212,6 +217,10 @@ private:
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
         const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false;
+        // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
+        float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
+        void *fb_s0 = nullptr, *fb_s1 = nullptr, *fb_x = nullptr; float *fb_first = nullptr, *fb_res = nullptr, *fb_part = nullptr;
+        int fb_B = 0, fb_L = 0, fb_Lt = 0, fb_C = 0; size_t fb_a_end = 0, fb_b_end = 0;
     };
     std::vector<PlanSnap> plan_cache;
     void plan_stash();                    // move the current plan into plan_cache (evicting the oldest beyond 4)

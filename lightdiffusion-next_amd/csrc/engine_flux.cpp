@@ -358,8 +358,11 @@ int Engine::run_flux(const float* x, const float* sigma, const float* ctx, const
     HIP_OK(hipSetDevice(device));
     if (B != pB2 || h != ph || w != pw || Lt != pM) {
         HIP_OK(hipStreamSynchronize(st));
-        int rc = plan_flux(B, h, w, Lt);
-        if (rc) return rc;
+        // plans (op list + arena) are kept per shape like the UNet's: the multi-scale samplers alternate two resolutions and prompts
+        // of different lengths change Lt; the first-block cache still resets on every shape change (fbcache_nodes.py:56-66)
+        if (pB2 > 0) plan_stash();
+        if (plan_restore(B, h, w, Lt)) fb_reset();
+        else { int rc = plan_flux(B, h, w, Lt); if (rc) return rc; }
     }
     b_x = x; b_s = sigma; b_ctx = ctx; b_y = y; b_guid = guidance; b_cos = pe_cos; b_sin = pe_sin; b_out = out; b_den = denoise;
     prof_graph = false;

@@ -25,11 +25,49 @@ constexpr int BK = 64;
 // that N = 320 / 960 / 1920 get with 128.
 template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
 
+// Folded LayerNorm, statistics side.  Every wave streams all K columns of its rows through its A fragments, so the row sums come out of
+// one extra MFMA per fragment, next to the real ones and with the same exact fp32 accumulation: the wave with wn = 0 issues ones x A^T
+// (every accumulator row = sum_k a[m][k]), its neighbour with wn = 1 issues A x A^T (diagonal = sum_k a[m][k]^2); after the K loop the two
+// exchange through LDS.  No pass over the activation, nothing crosses workgroups, fixed order.  (First version: v_dot2c_f32 on every
+// pair, both waves: 64 VALU dot products per K-tile next to 40 MFMAs made the q|k|v projection VALU-bound, 50 -> 74 us at level 0.)
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 ones_v8() {
+    typename Vec<T>::v8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)1.0f;
+    return o;
+}
+// st: LDS scratch of 2 * ROWS floats (free after the K loop); on return s1 / s2 hold mean and 1 / sqrt(var + eps) of the lane's MI rows.
+// lnacc[i] of a wn = 0 wave: any element = the row sum; of a wn = 1 wave: element l15 & 3 on the lanes with g4 == l15 >> 2 = the sum of squares.
+template <int MI, int ROWS>
+__device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st, const int wrow0, const int wn, const int l15, const int g4,
+                                            const int K, const float eps, float (&mean)[MI], float (&rstd)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wrow0 + i * 16 + l15;
+        if (wn == 0) { if (g4 == 0) st[row] = lnacc[i][0]; }
+        else if (g4 == (l15 >> 2)) {
+            const int r = l15 & 3;
+            st[ROWS + row] = r == 0 ? lnacc[i][0] : r == 1 ? lnacc[i][1] : r == 2 ? lnacc[i][2] : lnacc[i][3];
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wrow0 + i * 16 + l15;
+        const float m = st[row] * inv;
+        mean[i] = m;
+        rstd[i] = rsqrtf(fmaxf(st[ROWS + row] * inv - m * m, 0.f) + eps);
+    }
+}
+
 // Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
-template <typename T, int BM, int BN, int WM, int MI, int NJ>
+// LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
-                                              const int l15, const int g4, const int split, const int S) {
+                                              const int l15, const int g4, const int split, const int S,
+                                              const float* lnm = nullptr, const float* lnr = nullptr) {
     // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
     if (S > 1) {
         float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
@@ -97,6 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
         if (m >= p.M) continue;
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
         const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
+        const float ln_mean = LNF ? lnm[i] : 0.f, ln_rstd = LNF ? lnr[i] : 1.f;
         if (BN != 128 || !p.geglu) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
@@ -105,6 +144,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 const bool full = (n + 3) < p.N;
                 if (full) {
+                    if (LNF) { const float4 c = *(const float4*)(p.ln_c1 + n);
+                                     v[0] = ln_rstd * (v[0] - ln_mean * c.x); v[1] = ln_rstd * (v[1] - ln_mean * c.y);
+                                     v[2] = ln_rstd * (v[2] - ln_mean * c.z); v[3] = ln_rstd * (v[3] - ln_mean * c.w); }
                     if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                     if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                     if (p.act == 1) {
@@ -127,6 +169,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                 } else {
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
                         float x = v[r];
+                        if (LNF) x = ln_rstd * (x - ln_mean * p.ln_c1[n + r]);
                         if (p.bias) x += p.bias[n + r];
                         if (rv) x += rv[n + r];
                         if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
@@ -152,6 +195,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                 float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
                 constexpr int JG = (BN == 128) ? 2 : 0;
                 float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
+                if (LNF) {
+                    const float4 ca = *(const float4*)(p.ln_c1 + na), cg = *(const float4*)(p.ln_c1 + ng);
+                    a[0] = ln_rstd * (a[0] - ln_mean * ca.x); a[1] = ln_rstd * (a[1] - ln_mean * ca.y); a[2] = ln_rstd * (a[2] - ln_mean * ca.z); a[3] = ln_rstd * (a[3] - ln_mean * ca.w);
+                    g[0] = ln_rstd * (g[0] - ln_mean * cg.x); g[1] = ln_rstd * (g[1] - ln_mean * cg.y); g[2] = ln_rstd * (g[2] - ln_mean * cg.z); g[3] = ln_rstd * (g[3] - ln_mean * cg.w);
+                }
                 if (p.bias) {
                     const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
                     a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
@@ -175,9 +223,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
 // F8: A / W are MX fp8 bytes (GemmArgs::f8): a K-tile is still 128 B per row = 128 elements, one 16x16x128 block-scaled MFMA
 // per (i, j) and K-tile instead of two 16x16x32; the E8M0 scales bypass LDS (one dword per row and K-tile, prefetched with
 // the tile).  Same LDS layout, staging, split-K and epilogue as the 16-bit kernel.
-template <typename T, int MODE, int BM, int BN, int WM, bool F8>
+template <typename T, int MODE, int BM, int BN, int WM, bool F8, bool LNF = false>
 __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int block) {
     static_assert(!F8 || MODE == 0, "MX fp8 operands: plain GEMM only");
+    static_assert(!LNF || (MODE == 0 && !F8), "folded LayerNorm: plain 16-bit GEMM only");
     constexpr int ES = F8 ? 1 : 2;              // bytes per A / W element
     constexpr int KE = 128 / ES;                // elements per K-tile (= BK for 16-bit)
     constexpr int CE = 16 / ES;                 // elements per 16-B staging chunk
@@ -354,6 +403,9 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 lnacc[LNF ? MI : 1];                           // folded LayerNorm: row sums (wn = 0) / sums of squares (wn = 1), see ln_exchange
+#pragma unroll
+    for (int i = 0; i < (LNF ? MI : 1); ++i) lnacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
 #ifndef LDX_GEMM_NO_T14
     // Staging schedule (guide T14): the registers always hold the NEXT tile's loads.  Top of iteration kt: write tile kt+1 to the
@@ -434,6 +486,10 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
                 const int ch = (ks * 4 + g4) ^ (row & 7);
                 af[i] = as_v8<T>(*(const uint4*)(sA + row * 128 + (ch << 4)));
             }
+            if constexpr (LNF) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) lnacc[i] = mfma16(wn ? af[i] : ones_v8<T>(), af[i], lnacc[i]);
+            }
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int row = wn * (BN / 2) + j * 16 + l15;
@@ -458,14 +514,20 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
         __syncthreads();
     }
 
-    gemm_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, m0, n0, wm, wn, l15, g4, split, S);
+    if constexpr (LNF) {
+        float ln1[MI], ln2[MI];
+        ln_exchange<MI, BM>(lnacc, (float*)smem, wm * (BM / WM), wn, l15, g4, p.K, p.ln_eps, ln1, ln2);     // the K loop ended with a barrier
+        gemm_epilogue<T, BM, BN, WM, MI, NJ, true>(p, acc, m0, n0, wm, wn, l15, g4, split, S, ln1, ln2);
+    } else {
+        gemm_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, m0, n0, wm, wn, l15, g4, split, S);
+    }
 }
 
 #include "gemm_pp.inc"
 
-template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false, bool LNF = false>
 __global__ __launch_bounds__(WM * 128, WM == 2 ? 2 : 1) void gemm_kernel(const GemmArgs p) {
-    gemm_tile_body<T, MODE, BM, BN, WM, F8>(p, blockIdx.x);
+    gemm_tile_body<T, MODE, BM, BN, WM, F8, LNF>(p, blockIdx.x);
 }
 // Two independent plain GEMMs in one launch (Flux double blocks: the 4096-row image stream and the 256-row text stream run the
 // same layer shapes with different weights): the second problem's tiles are appended to the first's, so they fill the
@@ -583,21 +645,21 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
     return {128, bn};
 }
 
-template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false>
+template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false, bool LNF = false>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * stage_bytes<BM, BN>();
     static DevOnce once;
-    set_dyn_lds(once, (const void*)gemm_kernel<T, MODE, BM, BN, WM, F8>, (int)lds);
-    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8>), dim3(tiles), dim3(WM * 128), lds, s, a);
+    set_dyn_lds(once, (const void*)gemm_kernel<T, MODE, BM, BN, WM, F8, LNF>, (int)lds);
+    hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8, LNF>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
-template <typename T, int MODE, int BN>
+template <typename T, int MODE, int BN, bool LNF = false>
 static void launch_gemm_pp_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * S;
     static DevOnce once;
-    set_dyn_lds(once, (const void*)gemm_pp_kernel<T, MODE, BN>, PP_LDS);
-    hipLaunchKernelGGL((gemm_pp_kernel<T, MODE, BN>), dim3(tiles), dim3(512), PP_LDS, s, a);
+    set_dyn_lds(once, (const void*)gemm_pp_kernel<T, MODE, BN, LNF>, PP_LDS);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, MODE, BN, LNF>), dim3(tiles), dim3(512), PP_LDS, s, a);
 }
 
 template <typename T, int MODE>
@@ -611,6 +673,16 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
         return;
     }
     const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
+    if constexpr (MODE == 0) {
+        if (a.ln_c1) {       // LayerNorm folded in (no split-K): the tile shapes a transformer block's q|k|v / q / GEGLU projections take
+            if (t.bm == 256 && t.bn != 128 && !a.geglu) launch_gemm_pp_inst<T, 0, 160, true>(a, 1, s);
+            else if (t.bm == 256) launch_gemm_pp_inst<T, 0, 128, true>(a, 1, s);
+            else if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, false, true>(a, 1, s);
+            else if (t.bn == 160 && !a.geglu) launch_gemm_inst<T, 0, 128, 160, 2, false, true>(a, 1, s);
+            else launch_gemm_inst<T, 0, 128, 128, 2, false, true>(a, 1, s);
+            return;
+        }
+    }
     if (t.bm == 256 && t.bn == 256 && !a.geglu) launch_gemm_pp_inst<T, MODE, 256>(a, S, s);
     else if (t.bm == 256 && t.bn == 160 && !a.geglu) launch_gemm_pp_inst<T, MODE, 160>(a, S, s);
     else if (t.bm == 256) launch_gemm_pp_inst<T, MODE, 128>(a, S, s);

@@ -65,6 +65,10 @@ struct GemmArgs {
     // bytes C8[m][c8_col + n], scales SC (SA layout, row stride sc_ld) for the blocks (c8_col + n) / 32 — the operand of the
     // next block-scaled GEMM, produced without a separate quantisation pass
     void* C8; int ldc8; int c8_col; uint32_t* SC; int sc_ld;
+    // ln_c1 != null: a LayerNorm over the K columns is folded into this plain 16-bit GEMM (no split-K): A = the UN-normalised rows,
+    // W = W .* gamma, bias = W beta + b, ln_c1[n] = sum_k W[n][k] of the stored 16-bit values.  The kernel accumulates each row's
+    // sum / sum of squares from its A fragments and stores  rstd[m] * (acc - mean[m] * ln_c1[n]) + bias[n]  (then GEGLU etc.)
+    const float* ln_c1; float ln_eps;
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
                                    // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
 };

@@ -152,3 +152,35 @@ def test_determinism_and_errors(setup, ldx):
         ldx.UNetEngine(cfg, bad, device=0)
     with pytest.raises(ldx.lib.LdxError):
         ldx.UNetEngine(ldx.UNetConfig.tiny(32, 64), sd, device=0)       # model_channels % 64 != 0
+
+
+def test_folded_layernorm_mode_vs_oracle(ldx_lib):
+    """LDX_LNFOLD=1 (norm1/2/3 folded into the q|k|v / q / GEGLU projections: row statistics from the GEMM's own A fragments,
+    rstd * (acc - mean * c1) + c2 in the epilogue) is read once per process -> checked in a subprocess, tiny UNet vs the oracle,
+    both activation modes, an odd latent size included."""
+    import subprocess, sys, textwrap
+    code = textwrap.dedent('''
+        import sys, torch
+        sys.path.insert(0, %r)
+        import ldx_amd as ldx
+        from oracle import sd15_oracle as O
+        cfg = ldx.UNetConfig.tiny(64, 128)
+        sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234)
+        g = torch.Generator().manual_seed(3)
+        for (h, w) in ((16, 16), (18, 12)):
+            x = torch.randn([2, 4, h, w], generator=g); sigma = torch.tensor([3.0, 0.7]); ctx = torch.randn([2, 154, 128], generator=g)
+            with torch.no_grad():
+                ref = O.apply_model(sd, cfg, x, sigma, ctx)
+            for dt, tol in (("f16", 4e-3), ("bf16", 2.5e-2)):
+                eng = ldx.UNetEngine(cfg, sd, device=0, dtype=dt)
+                n0 = eng.plan_info()["launches"] if False else None
+                out = eng.denoise(x.cuda(), sigma.cuda(), ctx.cuda()).cpu()
+                rel = float((out - ref).norm() / ref.norm())
+                print(dt, h, w, rel, eng.plan_info()["launches"])
+                assert rel <= tol, (dt, rel)
+        print("FOLD_OK")
+    ''') % os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LDX_LNFOLD="1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    print(r.stdout[-2000:], r.stderr[-2000:])
+    assert r.returncode == 0 and "FOLD_OK" in r.stdout

@@ -146,3 +146,19 @@ def test_flux_hook_contract(ldx, flux, golden_dir, dt, tol):
         assert r <= tol
     with pytest.raises(ValueError):
         patch(None, {"input": T("input"), "timestep": T("timestep"), "c": {"c_crossattn": T("ctx")}, "cond_or_uncond": [1, 0]})
+
+
+def test_flux_plan_cache_round_trip(ldx, flux):
+    """Plans are kept per input shape (multi-scale samplers alternate two resolutions, prompts change the text length):
+    A -> B -> A must reproduce A's first result bit for bit, and so must B, with different latent sizes AND text lengths."""
+    cfg, sd, g = flux
+    eng = ldx.FluxEngine(cfg, sd, device=0, dtype="bf16")
+    gen = torch.Generator().manual_seed(9)
+    mk = lambda h, w, lt: (torch.randn(1, cfg.in_channels, h, w, generator=gen).cuda(), torch.tensor([0.6]).cuda(),
+                           torch.randn(1, lt, cfg.context_in_dim, generator=gen).cuda(), torch.randn(1, cfg.vec_in_dim, generator=gen).cuda(),
+                           torch.tensor([3.0]).cuda())
+    a, b, c = mk(16, 16, 24), mk(8, 8, 24), mk(16, 16, 40)
+    ya, yb, yc = eng.forward(*a).clone(), eng.forward(*b).clone(), eng.forward(*c).clone()
+    for _ in range(2):
+        assert torch.equal(eng.forward(*a), ya) and torch.equal(eng.forward(*b), yb) and torch.equal(eng.forward(*c), yc)
+    assert torch.isfinite(ya).all() and ya.shape == a[0].shape and yb.shape == b[0].shape
