@@ -654,17 +654,45 @@ static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
     hipLaunchKernelGGL((gemm_kernel<T, MODE, BM, BN, WM, F8, LNF>), dim3(tiles), dim3(WM * 128), lds, s, a);
 }
 
-template <typename T, int MODE, int BN, bool LNF = false>
+template <typename T, int MODE, int BN, bool LNF = false, bool F8 = false>
 static void launch_gemm_pp_inst(const GemmArgs& a, int S, hipStream_t s) {
     const int tiles = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN) * S;
     static DevOnce once;
-    set_dyn_lds(once, (const void*)gemm_pp_kernel<T, MODE, BN, LNF>, PP_LDS);
-    hipLaunchKernelGGL((gemm_pp_kernel<T, MODE, BN, LNF>), dim3(tiles), dim3(512), PP_LDS, s, a);
+    set_dyn_lds(once, (const void*)gemm_pp_kernel<T, MODE, BN, LNF, F8>, PP_LDS);
+    hipLaunchKernelGGL((gemm_pp_kernel<T, MODE, BN, LNF, F8>), dim3(tiles), dim3(512), PP_LDS, s, a);
+}
+// MX fp8 operands: 256-row ping-pong tile width (160 / 128) or 0 = keep the 128-row kernel.  Same cost model as gemm_tile with the MX
+// rates (isolated Flux shapes, profiles/mx_probe.py); the quantised-output epilogue needs 64-column wave tiles (BN = 128).
+static int mx_pp_bn(long tiles_m256, long tiles_m128, int N, int K, int S, bool c8, long extra160 = 0, long extra128 = 0, long extra_old = 0) {
+    static const int pp_policy = getenv("LDX_PP") ? atoi(getenv("LDX_PP")) : 1;
+    static const int pp_mink = getenv("LDX_PP_MINK_MX") ? atoi(getenv("LDX_PP_MINK_MX")) : 2048;
+    if (!pp_policy || N < 256 || K < pp_mink) return 0;
+    double best = 1e30; int best_bn = 0;
+    const int cand[2] = {160, 128};
+    const double rate[2] = {2.0, 1.75};
+    for (int c = 0; c < 2; ++c) {
+        if (c8 && cand[c] != 128) continue;
+        const long t = tiles_m256 * ((N + cand[c] - 1) / cand[c]) * S + (c == 0 ? extra160 : extra128);
+        if (t < 192) continue;
+        const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
+        if (cost < best) { best = cost; best_bn = cand[c]; }
+    }
+    if (!best_bn) return 0;
+    const long to = tiles_m128 * ((N + 127) / 128) * S + extra_old;
+    const double cost_old = (double)((to + 511) / 512) * 512.0 * 128.0 * 128.0 / 1.2;
+    return (pp_policy >= 2 || best < 0.95 * cost_old) ? best_bn : 0;
 }
 
 template <typename T, int MODE>
 static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
+        if constexpr (MODE == 0) {
+            static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;
+            const int bn = force ? (force / 1000 == 256 ? (a.C8 ? 128 : (force % 1000 == 160 ? 160 : 128)) : 0)
+                                 : (a.M >= 1024 ? mx_pp_bn((a.M + 255) / 256, (a.M + 127) / 128, a.N, a.K, S, a.C8 != nullptr) : 0);
+            if (bn == 160) { launch_gemm_pp_inst<T, 0, 160, false, true>(a, S, s); return; }
+            if (bn == 128) { launch_gemm_pp_inst<T, 0, 128, false, true>(a, S, s); return; }
+        }
         const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S, false);      // no MX ping-pong kernel yet (256 x 128 only when forced)
         if (t.bm == 256 && t.bn == 128) launch_gemm_inst<T, 0, 256, 128, 4, true>(a, S, s);      // opt-in (LDX_TILE256)
         else if (t.bm == 64) launch_gemm_inst<T, 0, 64, 64, 2, true>(a, S, s);
@@ -737,12 +765,12 @@ static void launch_gemm2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) 
     set_dyn_lds(once, (const void*)gemm2_kernel<T, 128, 128, F8>, (int)lds);
     hipLaunchKernelGGL((gemm2_kernel<T, 128, 128, F8>), dim3(ta + tb), dim3(256), lds, s, a, b, ta);
 }
-template <typename T, int BN>
+template <typename T, int BN, bool F8 = false>
 static void launch_gemm_pp2_t(const GemmArgs& a, const GemmArgs& b, hipStream_t s) {
     const int ta = ((a.M + 255) / 256) * ((a.N + BN - 1) / BN), tb = ((b.M + 255) / 256) * ((b.N + BN - 1) / BN);
     static DevOnce once;
-    set_dyn_lds(once, (const void*)gemm_pp2_kernel<T, BN>, PP_LDS);
-    hipLaunchKernelGGL((gemm_pp2_kernel<T, BN>), dim3(ta + tb), dim3(512), PP_LDS, s, a, b, ta);
+    set_dyn_lds(once, (const void*)gemm_pp2_kernel<T, BN, F8>, PP_LDS);
+    hipLaunchKernelGGL((gemm_pp2_kernel<T, BN, F8>), dim3(ta + tb), dim3(512), PP_LDS, s, a, b, ta);
 }
 // 256-row ping-pong tiles for a two-problem launch: same cost model as gemm_tile over the combined tile count; 0 = keep 128 x 128
 static int gemm2_pp_bn(const GemmArgs& a, const GemmArgs& b) {
@@ -768,6 +796,14 @@ void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s)
     if (a.M <= 0 || a.N <= 0) { launch_gemm(b, dt, s); return; }
     if (b.M <= 0 || b.N <= 0) { launch_gemm(a, dt, s); return; }
     GemmArgs x = a, y = b; x.splitk = y.splitk = 1;
+    if (x.f8 && y.f8 && x.M + y.M >= 1024 && y.N >= 256) {       // MX: the two streams of a Flux double block / the two halves of linear1
+        const bool c8 = x.C8 || y.C8;
+        const long ym256 = (y.M + 255) / 256, ym128 = (y.M + 127) / 128;
+        const int bn = mx_pp_bn((x.M + 255) / 256, (x.M + 127) / 128, x.N, x.K < y.K ? x.K : y.K, 1, c8,
+                                ym256 * ((y.N + 159) / 160), ym256 * ((y.N + 127) / 128), ym128 * ((y.N + 127) / 128));
+        if (bn == 160) { if (dt == DT_BF16) launch_gemm_pp2_t<__bf16, 160, true>(x, y, s); else launch_gemm_pp2_t<_Float16, 160, true>(x, y, s); return; }
+        if (bn == 128) { if (dt == DT_BF16) launch_gemm_pp2_t<__bf16, 128, true>(x, y, s); else launch_gemm_pp2_t<_Float16, 128, true>(x, y, s); return; }
+    }
     if (const int bn = gemm2_pp_bn(x, y)) {
         if (dt == DT_BF16) { if (bn == 256) launch_gemm_pp2_t<__bf16, 256>(x, y, s); else if (bn == 160) launch_gemm_pp2_t<__bf16, 160>(x, y, s); else launch_gemm_pp2_t<__bf16, 128>(x, y, s); }
         else { if (bn == 256) launch_gemm_pp2_t<_Float16, 256>(x, y, s); else if (bn == 160) launch_gemm_pp2_t<_Float16, 160>(x, y, s); else launch_gemm_pp2_t<_Float16, 128>(x, y, s); }
