@@ -1,7 +1,7 @@
 #!/bin/bash
 # Run on the GPU box (via gpurun): rocprofv3 kernel-trace stats of bench.py + separate PMC passes (FETCH_SIZE /
 # WRITE_SIZE, never combined with trace domains) on the dominant kernels.  Output -> gpurun_out/prof_$1/
-TAG=${1:-r01}
+TAG=${1:-r02}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -19,7 +19,7 @@ fs = glob.glob("/tmp/pm/**/*counter_collection.csv", recursive=True)
 acc = collections.defaultdict(lambda: [0.0, set()])
 for r in csv.DictReader(open(fs[0])):
     n = r["Kernel_Name"]
-    if "ldx" in n and ("attn" in n or "gemm_kernel" in n):
+    if "ldx" in n and ("attn" in n or "gemm_kernel" in n or "gemm_pp_kernel" in n):
         a = acc[n]; a[0] += float(r["Counter_Value"]); a[1].add(r["Dispatch_Id"])
 for n, (v, d) in acc.items():
     print(f"{sys.argv[1]} {sys.argv[2]} per-dispatch={v/len(d):.1f} dispatches={len(d)} kernel={n[:80]}")

@@ -127,3 +127,15 @@ if __name__ == "__main__":
         for (M, N, K) in ((2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320), (512, 1280, 1280)):
             wn = max(1, int(400e6 / (N * K * 2))); an = max(1, int(400e6 / (M * K * 2)))
             gemm_cold(M, N, K, 1, 1); gemm_cold(M, N, K, 1, wn); gemm_cold(M, N, K, an, 1); gemm_cold(M, N, K, an, wn)
+    if what == "deep":     # weight-streaming convs / GEMMs of the deep UNet levels (M = 512 / 2048): run with LDX_GEMM_TILE / LDX_SPLITK sweeps
+        def convg(B, H, Cin, Cout):
+            X = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
+            Ws = [torch.randn(Cout, 9 * Cin, device="cuda").bfloat16() for _ in range(max(1, int(600e6 / (Cout * 9 * Cin * 2))))]   # cold weights
+            Y = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.bfloat16)
+            i = [0]
+            def fn():
+                w = Ws[i[0] % len(Ws)]; i[0] += 1
+                L.ldx_op_conv3x3(p(X), Cin, p(w), B, H, H, Cin, Cout, 1, H, H, 0, None, None, 0, None, 0, p(Y), Cout, 0, st())
+            ms = timeit_graph(fn, reps=len(Ws) * 2)
+            print(f"conv B{B} {H}x{H} {Cin}->{Cout} (cold W x{len(Ws)}): {ms * 1000:.1f} us  {2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9:.1f} TFLOP/s  W {Cout * 9 * Cin * 2 / ms / 1e6:.0f} GB/s")
+        convg(2, 16, 1280, 1280); convg(2, 16, 2560, 1280); convg(2, 32, 1280, 1280); convg(2, 32, 2560, 1280); convg(2, 32, 1920, 1280); convg(2, 64, 1280, 640)
