@@ -319,7 +319,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 // 8*(s&1)..+7 of key tile s>>1 straight back as the P^T operand of k-step s makes k-slot 8h+e stand for key
 // 16s + (e < 4 ? 4h + e : 8 + 4h + e - 4); the V^T operand is gathered in exactly that order by two ds_read_b64_tr_b16 per
 // 16-lane group (keys 16s + 4h + 0..3 and 16s + 8 + 4h + 0..3, 16 d columns each).
-template <typename T, int KVB, int KROWB, int VROWB>       // KVB keys per LDS stage (64 or 128): one barrier + one staging round per KVB keys
+template <typename T, int KVB, int KROWB, int VROWB, int VAR = 0>       // KVB keys per LDS stage (64 or 128): one barrier + one staging round per KVB keys
 __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     constexpr int QW = 64, QB = 256;                 // queries per wave / workgroup
     // LDS row strides (PMC: SQ_LDS_BANK_CONFLICT).  K rows are read 16 B per lane by 16 different rows at one chunk column: the
@@ -445,6 +445,22 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
             asm volatile("" ::: "memory");           // keep this a branch: if-conversion would run 64 selects every key block
         }
 
+        // VAR 1: the V^T fragments of this key block are fetched BEFORE the softmax, so that their LDS latency hides under its VALU work
+        // instead of stalling the first PV MFMAs (+32 VGPRs)
+        V8 vpre[VAR == 1 ? 4 : 1][VAR == 1 ? 2 : 1];
+        if constexpr (VAR == 1) {
+#pragma unroll
+            for (int st = 0; st < 4; ++st)
+#pragma unroll
+                for (int dt = 0; dt < 2; ++dt) {
+                    const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * VROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
+                    U128 vf;
+                    vf.d[0] = lds_read_tr16(vp);
+                    vf.d[1] = lds_read_tr16(vp + 8 * VROWB);
+                    vpre[st][dt] = as_v8<T>(vf.u);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
         // ---- online softmax; P packed as B-operand fragments: k-step st takes registers 8*(st&1)..+7 of key tile st>>1 ----
         V8 pf[2][4];
 #pragma unroll
@@ -484,10 +500,14 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
                 // 16-lane group g16: h' = g16 >> 1, d columns dt*32 + 16*(g16 & 1) + 0..15; lane i of the group addresses 4 contiguous d
                 // of key (i >> 2) and receives column d = .. + i for keys K0 + 0..3
                 const char* vp = sV + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * VROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
-                U128 vf;
-                vf.d[0] = lds_read_tr16(vp);
-                vf.d[1] = lds_read_tr16(vp + 8 * VROWB);
-                const V8 v8 = as_v8<T>(vf.u);
+                V8 v8;
+                if constexpr (VAR == 1) v8 = vpre[st][dt];
+                else {
+                    U128 vf;
+                    vf.d[0] = lds_read_tr16(vp);
+                    vf.d[1] = lds_read_tr16(vp + 8 * VROWB);
+                    v8 = as_v8<T>(vf.u);
+                }
 #pragma unroll
                 for (int qt = 0; qt < 2; ++qt) o[qt][dt] = mfma32(v8, pf[qt][st], o[qt][dt]);
             }
@@ -524,19 +544,21 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
     }
 }
 
-template <typename T, int KVB, int KROWB, int VROWB>
+template <typename T, int KVB, int KROWB, int VROWB, int VAR = 0>
 static void launch_attn32_k(const AttnArgs& a, hipStream_t s) {
     const size_t lds = 2 * KVB * (KROWB + VROWB);
     static DevOnce once;
-    set_dyn_lds(once, (const void*)attn32_kernel<T, KVB, KROWB, VROWB>, (int)lds);
+    set_dyn_lds(once, (const void*)attn32_kernel<T, KVB, KROWB, VROWB, VAR>, (int)lds);
     dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
-    hipLaunchKernelGGL((attn32_kernel<T, KVB, KROWB, VROWB>), grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL((attn32_kernel<T, KVB, KROWB, VROWB, VAR>), grid, dim3(256), lds, s, a);
 }
 template <typename T>
 static void launch_attn32(const AttnArgs& a, hipStream_t s) {
     static const int kvb = getenv("LDX_ATTN32_KVB") ? atoi(getenv("LDX_ATTN32_KVB")) : 64;       // experiment switch
     // strides 160 / 160 had 2-way conflicts on every fragment read (SQ_LDS_BANK_CONFLICT 88.1 M -> 21.0 M cycles per launch with 144 / 192;
     // same time at D = 40, which is VALU / MFMA bound)
+    static const int var = getenv("LDX_ATTN32_VAR") ? atoi(getenv("LDX_ATTN32_VAR")) : 1;               // 1: V^T fragments prefetched before the softmax (1.219 -> 1.206 ms at B2 H8 N16384, twice on one box); 0: read at the PV MFMAs
+    if (var == 1) { launch_attn32_k<T, 64, 144, 192, 1>(a, s); return; }
     if (kvb == 128 && a.Mk >= 1024) launch_attn32_k<T, 128, 144, 192>(a, s); else launch_attn32_k<T, 64, 144, 192>(a, s);
 }
 
@@ -873,7 +895,10 @@ static void launch_attn_t(const AttnArgs& a, hipStream_t s) {
     if constexpr (DT <= 3) {
         if ((long)((a.Nq + 255) / 256) * a.H * a.B >= 512 && !a.causal) { launch_attn_q<T, KS, DT, 4>(a, s); return; }
     }
-    launch_attn_q<T, KS, DT, 2>(a, s);
+    // D >= 144 (DT >= 10): two 16-query tiles per wave need 12 more VGPRs than the file has (40 B of scratch per lane, hipcc
+    // -Rpass-analysis): one tile per wave there.  Only small grids / masked calls get here (attn32g takes the rest).
+    if constexpr (DT >= 10) launch_attn_q<T, KS, DT, 1>(a, s);
+    else launch_attn_q<T, KS, DT, 2>(a, s);
 }
 
 template <typename T>

@@ -164,7 +164,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                     if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
                     if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
                                   v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
-                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);     // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
