@@ -1,0 +1,52 @@
+"""The 256-row ping-pong GEMM / implicit-GEMM main loop (csrc/gemm_pp.inc) on the op tests' shapes.
+
+The cost model only picks that kernel for large problems, which the op tests (odd sizes, ragged M / N / K, stride 2, nearest-resize,
+fused skip segment, split-K ranges that start inside the second K segment, GEGLU, MX fp8 operands and quantised output) are not.  The
+tile is forced with LDX_GEMM_TILE (read once per process), so each tile width runs the GEMM / conv / MX op tests in a subprocess: same
+tests, same torch-fp32 / fp64 references and tolerances, different kernel underneath (LDS-DMA zero-fill of out-of-range rows included)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("tile", ["256128", "256160", "256256"])
+def test_op_tests_on_forced_pingpong_tiles(ldx_lib, tile):
+    env = dict(os.environ, LDX_GEMM_TILE=tile)
+    sel = "test_gemm or test_conv3x3 or test_gemm_mx"
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_ops_gpu.py", "tests/test_mx_gpu.py", "-k", sel],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    print(tail, r.stderr[-500:])
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
+def test_large_shapes_pick_the_pingpong_kernel_and_match_torch(ldx, ldx_lib):
+    """Un-forced: shapes the cost model sends to the ping-pong kernel (plain GEMM with long K, 3x3 conv at the level-0 size), against
+    torch fp32 on the same 16-bit operands."""
+    import ctypes as C
+    import torch
+    L = ldx_lib
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    M, N, K = 4096, 1280, 2048
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16(); W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g); R = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    assert L.ldx_op_gemm(p(A), K, p(W), M, N, K, p(bias), None, 0, 1, 0, p(R), N, p(Cc), N, None, 0, 0, st) == 0
+    ref = A.float() @ W.float().t() + bias + R.float()
+    assert float((Cc.float() - ref).norm() / ref.norm()) < 4e-3
+    B, H, Cin, Cout = 2, 64, 320, 320
+    X = torch.randn(B, H, H, Cin, device="cuda", generator=g).bfloat16()
+    Wc = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / (9 * Cin) ** 0.5)
+    Wp = Wc.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous().bfloat16()
+    Y = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.bfloat16)
+    assert L.ldx_op_conv3x3(p(X), Cin, p(Wp), B, H, H, Cin, Cout, 1, H, H, 0, None, None, 0, None, 0, p(Y), Cout, 0, st) == 0
+    ref = torch.nn.functional.conv2d(X.float().permute(0, 3, 1, 2), Wp.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(B * H * H, Cout)
+    assert float((Y.float() - ref).norm() / ref.norm()) < 4e-3
