@@ -1,0 +1,206 @@
+// Device code shared by the two GEMM main loops (gemm.hip: register-staged 128-row tiles; gemm_pp.hip: 256-row ping-pong tiles):
+// K-tile constants, the folded-LayerNorm helpers and the output stage with every fused epilogue.
+#pragma once
+#include <stdlib.h>
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+constexpr int BK = 64;
+// BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
+// 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)
+// that N = 320 / 960 / 1920 get with 128.
+template <int BM, int BN> constexpr int stage_bytes() { return (BM + BN) * BK * 2; }
+
+// Folded LayerNorm, statistics side.  Every wave streams all K columns of its rows through its A fragments, so the row sums come out of
+// one extra MFMA per fragment, next to the real ones and with the same exact fp32 accumulation: the wave with wn = 0 issues ones x A^T
+// (every accumulator row = sum_k a[m][k]), its neighbour with wn = 1 issues A x A^T (diagonal = sum_k a[m][k]^2); after the K loop the two
+// exchange through LDS.  No pass over the activation, nothing crosses workgroups, fixed order.  (First version: v_dot2c_f32 on every
+// pair, both waves: 64 VALU dot products per K-tile next to 40 MFMAs made the q|k|v projection VALU-bound, 50 -> 74 us at level 0.)
+template <typename T> __device__ __forceinline__ typename Vec<T>::v8 ones_v8() {
+    typename Vec<T>::v8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = (T)1.0f;
+    return o;
+}
+// st: LDS scratch of 2 * ROWS floats (free after the K loop); on return s1 / s2 hold mean and 1 / sqrt(var + eps) of the lane's MI rows.
+// lnacc[i] of a wn = 0 wave: any element = the row sum; of a wn = 1 wave: element l15 & 3 on the lanes with g4 == l15 >> 2 = the sum of squares.
+template <int MI, int ROWS>
+__device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st, const int wrow0, const int wn, const int l15, const int g4,
+                                            const int K, const float eps, float (&mean)[MI], float (&rstd)[MI]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wrow0 + i * 16 + l15;
+        if (wn == 0) { if (g4 == 0) st[row] = lnacc[i][0]; }
+        else if (g4 == (l15 >> 2)) {
+            const int r = l15 & 3;
+            st[ROWS + row] = r == 0 ? lnacc[i][0] : r == 1 ? lnacc[i][1] : r == 2 ? lnacc[i][2] : lnacc[i][3];
+        }
+    }
+    __syncthreads();
+    const float inv = 1.0f / (float)K;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int row = wrow0 + i * 16 + l15;
+        const float m = st[row] * inv;
+        mean[i] = m;
+        rstd[i] = rsqrtf(fmaxf(st[ROWS + row] * inv - m * m, 0.f) + eps);
+    }
+}
+
+// Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
+// Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
+// LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
+                                              const int l15, const int g4, const int split, const int S,
+                                              const float* lnm = nullptr, const float* lnr = nullptr) {
+    // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
+    if (S > 1) {
+        float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+            if (m >= p.M) continue;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
+            }
+        }
+        return;
+    }
+    // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
+    if (p.C8) {
+        if constexpr ((BN / 2) % 32 == 0) {
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+                const bool live = m < p.M;                      // no early exit: every lane takes part in the exchanges
+#pragma unroll
+                for (int jp = 0; jp < NJ / 2; ++jp) {
+                    const int n = n0 + wn * (BN / 2) + jp * 32 + 4 * g4;
+                    const bool nok = n < p.N;                   // N % 32 == 0: a block is inside or outside as a whole
+                    float v[8];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
+                    if (p.bias && nok) {
+                        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 16);
+                        v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
+                    }
+                    float amax = 0.f;
+#pragma unroll
+                    for (int r = 0; r < 8; ++r) {
+                        if (p.act == 1) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                        else if (p.act == 2) v[r] = gelu_tanh_f(v[r]);
+                        else if (p.act == 3) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                        v[r] = to_f32(from_f32<T>(v[r]));       // the value the 16-bit path would have stored (same input to the quantiser)
+                        amax = fmaxf(amax, fabsf(v[r]));
+                    }
+                    amax = fmaxf(amax, __shfl_xor(amax, 16));
+                    amax = fmaxf(amax, __shfl_xor(amax, 32));
+                    const int e = mx_scale_e8m0(amax);
+                    const float inv = mx_inv_scale(e);
+                    if (live && nok) {
+                        char* dst = (char*)p.C8 + (long)m * p.ldc8 + p.c8_col + n;
+                        *(uint32_t*)dst = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+                        *(uint32_t*)(dst + 16) = mx_pack4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+                        if (g4 == 0) { const int kb = (p.c8_col + n) >> 5; ((uint8_t*)p.SC)[((long)(kb >> 2) * p.sc_ld + m) * 4 + (kb & 3)] = (uint8_t)e; }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
+    const T* __restrict__ Rp = (const T*)p.R;
+    T* __restrict__ Cp = (T*)p.C;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+        if (m >= p.M) continue;
+        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
+        const float ln_mean = LNF ? lnm[i] : 0.f, ln_rstd = LNF ? lnr[i] : 1.f;
+        if (BN != 128 || !p.geglu) {
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                if (n >= p.N) continue;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                const bool full = (n + 3) < p.N;
+                if (full) {
+                    if (LNF) { const float4 c = *(const float4*)(p.ln_c1 + n);
+                                     v[0] = ln_rstd * (v[0] - ln_mean * c.x); v[1] = ln_rstd * (v[1] - ln_mean * c.y);
+                                     v[2] = ln_rstd * (v[2] - ln_mean * c.z); v[3] = ln_rstd * (v[3] - ln_mean * c.w); }
+                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                    if (p.act == 1) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                    } else if (p.act == 2) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                    } else if (p.act == 3) {
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                    }
+                    if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                    if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
+                    if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                    if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
+                                  v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
+                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);     // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
+                    if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        float x = v[r];
+                        if (LNF) x = ln_rstd * (x - ln_mean * p.ln_c1[n + r]);
+                        if (p.bias) x += p.bias[n + r];
+                        if (rv) x += rv[n + r];
+                        if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+                        else if (p.act == 2) x = gelu_tanh_f(x);
+                        else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+                        if (gt) x *= gt[n + r];
+                        if (p.oscale != 0.f) x *= p.oscale;
+                        if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
+                        if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
+                        if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
+                        if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
+                    }
+                }
+            }
+        } else if (BN == 128) {
+            // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int na = n0 + wn * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
+                const int ng = na + 32;                                // GEMM column of 'g'
+                if (ng >= p.N) continue;
+                const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
+                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                constexpr int JG = (BN == 128) ? 2 : 0;
+                float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
+                if (LNF) {
+                    const float4 ca = *(const float4*)(p.ln_c1 + na), cg = *(const float4*)(p.ln_c1 + ng);
+                    a[0] = ln_rstd * (a[0] - ln_mean * ca.x); a[1] = ln_rstd * (a[1] - ln_mean * ca.y); a[2] = ln_rstd * (a[2] - ln_mean * ca.z); a[3] = ln_rstd * (a[3] - ln_mean * ca.w);
+                    g[0] = ln_rstd * (g[0] - ln_mean * cg.x); g[1] = ln_rstd * (g[1] - ln_mean * cg.y); g[2] = ln_rstd * (g[2] - ln_mean * cg.z); g[3] = ln_rstd * (g[3] - ln_mean * cg.w);
+                }
+                if (p.bias) {
+                    const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
+                    a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
+                    g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
+                }
+                float v[4];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = a[r] * (p.geglu == 2 ? gelu_tanh_f(g[r]) : gelu_erf_f(g[r]));
+                if (Cp) *(uint2*)(Cp + (long)m * p.ldc + no) = pack4<T>(v[0], v[1], v[2], v[3]);
+                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+}
+
+}  // namespace ldx

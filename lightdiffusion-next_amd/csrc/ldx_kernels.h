@@ -76,6 +76,9 @@ void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
 // two independent plain GEMMs (mode 0, no split-K / GEGLU, both 16-bit or both MX) as one launch of 128x128 tiles
 void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s);
 int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
+// 256-row ping-pong tiles (gemm_pp.hip; chosen by launch_gemm's cost model): bn = 128 / 160 / 256 tile width, lnf = GemmArgs::ln_c1 fold, S = K splits
+void launch_gemm_pp(const GemmArgs& a, int bn, bool lnf, int S, DType dt, hipStream_t s);
+void launch_gemm_pp2(const GemmArgs& a, const GemmArgs& b, int bn, DType dt, hipStream_t s);
 
 // MX quantisation of a 16-bit [rows][K] matrix (row stride ldx): per 32-element block, scale = 2^ceil(log2(amax / 448))
 // (E8M0, no clipping), y = e4m3fn(x / scale).  Y [rows][ldy] bytes; S as GemmArgs::SA (dwords [K/128][s_ld]).  K % 128 == 0.
