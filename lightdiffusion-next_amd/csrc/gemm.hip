@@ -210,6 +210,21 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
     for (int i = 0; i < MI; ++i)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Residual operand (GemmArgs::R) fetched NOW instead of in the epilogue: its latency hides under the K loop (the short-K projections of the
+    // transformer blocks spend a visible part of their time waiting for it after the last MFMA).  Only full 4-column groups of live rows are
+    // prefetched, the same predicate the epilogue's vector path uses; split-K and GEGLU launches keep the late read.
+    constexpr bool RPRE = !F8 && MI * NJ <= 20;
+    uint2 rpre[RPRE ? MI * NJ : 1];
+    const bool use_rpre = RPRE && p.R && p.splitk <= 1 && !p.geglu && !p.C8;
+    if (use_rpre) {
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + l15, n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                rpre[i * NJ + j] = (m < p.M && n + 3 < p.N) ? *(const uint2*)((const T*)p.R + (long)m * p.ldr + n) : make_uint2(0u, 0u);
+            }
+    }
     f32x4 lnacc[LNF ? MI : 1];                           // folded LayerNorm: row sums (wn = 0) / sums of squares (wn = 1), see ln_exchange
 #pragma unroll
     for (int i = 0; i < (LNF ? MI : 1); ++i) lnacc[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -326,7 +341,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
         ln_exchange<MI, BM>(lnacc, (float*)smem, wm * (BM / WM), wn, l15, g4, p.K, p.ln_eps, ln1, ln2);     // the K loop ended with a barrier
         gemm_epilogue<T, BM, BN, WM, MI, NJ, true>(p, acc, m0, n0, wm, wn, l15, g4, split, S, ln1, ln2);
     } else {
-        gemm_epilogue<T, BM, BN, WM, MI, NJ>(p, acc, m0, n0, wm, wn, l15, g4, split, S);
+        gemm_epilogue<T, BM, BN, WM, MI, NJ, false, RPRE ? MI * NJ : 1>(p, acc, m0, n0, wm, wn, l15, g4, split, S, nullptr, nullptr, rpre, use_rpre);
     }
 }
 

@@ -52,10 +52,10 @@ __device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st,
 // Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
 // LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
-template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false>
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, int NR = 1>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
                                               const int l15, const int g4, const int split, const int S,
-                                              const float* lnm = nullptr, const float* lnr = nullptr) {
+                                              const float* lnm, const float* lnr, const uint2 (&rpre)[NR], const bool use_rpre) {
     // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
     if (S > 1) {
         float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
@@ -149,7 +149,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                     }
                     if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
                     if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                    if (Rp)     { float r[4]; unpack4<T>(*(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                    if (Rp)     { float r[4]; unpack4<T>((NR > 1 && use_rpre) ? rpre[NR > 1 ? i * NJ + j : 0] : *(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
                     if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
                                   v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
                     if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);     // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
@@ -201,6 +201,14 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
             }
         }
     }
+}
+
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
+                                              const int l15, const int g4, const int split, const int S,
+                                              const float* lnm = nullptr, const float* lnr = nullptr) {
+    const uint2 none[1] = {make_uint2(0u, 0u)};
+    gemm_epilogue<T, BM, BN, WM, MI, NJ, LNF, 1>(p, acc, m0, n0, wm, wn, l15, g4, split, S, lnm, lnr, none, false);
 }
 
 }  // namespace ldx
