@@ -308,6 +308,8 @@ bool Engine::mk_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     return true;
 }
 
+static inline bool q_prescale() { static const bool on = getenv("LDX_NO_QPRESCALE") == nullptr; return on; }
+
 bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
     x.C = C; x.depth = depth;
     const int ctx = cfg.context_dim;
@@ -330,20 +332,25 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         // them (50 -> 66 us; the statistics MFMAs, the LDS exchange and the epilogue add 8 more) - profiles/ubench/README.md.  Off by default.
         static const bool fold_env = getenv("LDX_LNFOLD") != nullptr && atoi(getenv("LDX_LNFOLD")) != 0;
         b.ln_fold = fold_env;
+        // softmax_scale * log2(e) folded into the q projections at load time (one rounding of c * Wq instead of rounding q and multiplying
+        // every score): the attention ops then run with scale = 1 / log2(e), i.e. exp2(q.k - m) as before; LDX_NO_QPRESCALE=1 keeps the plain weights
+        const float cq = q_prescale() ? (1.0f / std::sqrt((float)(C / cfg.num_heads))) * 1.44269504088896340736f : 1.0f;
         auto qkv_w = [&](size_t r, size_t c) {
             const HostTensor* s = r < (size_t)C ? q : (r < (size_t)2 * C ? k : v);
-            return s->at((r % C) * C + c);
+            return s->at((r % C) * C + c) * (r < (size_t)C ? cq : 1.0f);
         };
         const HostTensor* q2w = get(bp + ".attn2.to_q.weight", {C, C});
         if (!q2w) return false;
         if (b.ln_fold) {
             if (!mk_ln_folded(3 * C, C, qkv_w, nullptr, bp + ".norm1", b.qkv, b.c1_qkv)) return false;
-            if (!mk_ln_folded(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c); }, nullptr, bp + ".norm2", b.q2, b.c1_q2)) return false;
+            if (!mk_ln_folded(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c) * cq; }, nullptr, bp + ".norm2", b.q2, b.c1_q2)) return false;
         } else {
             b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.b = nullptr;
             b.qkv.w = upload16((size_t)3 * C, C, qkv_w);
             if (!b.qkv.w) return false;
-            if (!mk_linear(bp + ".attn2.to_q", C, C, false, b.q2)) return false;
+            b.q2.N = C; b.q2.K = C; b.q2.b = nullptr;
+            b.q2.w = upload16(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c) * cq; });
+            if (!b.q2.w) return false;
         }
         if (!mk_linear(bp + ".attn1.to_out.0", C, C, true, b.o1)) return false;
         const HostTensor* k2 = get(bp + ".attn2.to_k.weight", {C, ctx});
@@ -648,6 +655,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         Act a = new_act(M, C);
         const char* base = (const char*)ptr(qkv);
         op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
+        if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
         release(qkv);
         op_gemm("xf.o1", a, b.o1, h, h);                       // x += attn1(norm1(x))   (in place)
         Act q = new_act(M, C);
@@ -655,6 +663,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
         op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
+        if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
         release(q);
         op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
         release(a);
