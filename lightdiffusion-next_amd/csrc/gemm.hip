@@ -18,9 +18,6 @@
 
 namespace ldx {
 
-template <typename T> struct DTypeOf;
-template <> struct DTypeOf<__bf16> { static constexpr DType v = DT_BF16; };
-template <> struct DTypeOf<_Float16> { static constexpr DType v = DT_F16; };
 
 // BM x BN workgroup tile, 4 waves as 2x2, each wave (BM/2) x (BN/2) = MI x NJ MFMA tiles of 16x16.
 // 128x128 / 128x160 for large problems; 64x64 for short-K problems whose 128-wide tiling would leave most CUs
@@ -417,7 +414,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 
 // tile selection: {BM, BN}
 struct TileSel { int bm, bn; };
-static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, bool allow_pp = true) {
+static const double pp_r224 = getenv("LDX_PP224_RATE") ? atof(getenv("LDX_PP224_RATE")) : 1.33, pp_r192 = getenv("LDX_PP192_RATE") ? atof(getenv("LDX_PP192_RATE")) : 1.29;   // 0: never
+static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, bool allow_pp = true, bool plain = false) {      // plain: a GEMM (224 / 192 wide ping-pong tiles exist), not a conv
     static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;      // experiment switch: BM*1000+BN
     if (force) return {force / 1000, force % 1000};
     if (!geglu && N <= 32 && splitk <= 1) return {128, 32};          // ESRGAN dense-block convs (growth 32), 3-channel output convs
@@ -432,10 +430,10 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
     if (allow_pp && pp_policy && M >= 1024 && N >= 256 && K >= pp_mink && !(geglu && K < 1024)) {
         const long S = splitk > 1 ? splitk : 1, mt = (M + 255) / 256;
         double best = 1e30; int best_bn = 0;
-        const int cand[3] = {256, 160, 128};
-        const double rate[3] = {1.35, 1.15, 0.92};
-        for (int c = 0; c < 3; ++c) {
-            if (geglu && cand[c] != 128) continue;
+        const int cand[5] = {256, 224, 192, 160, 128};
+        const double rate[5] = {1.35, plain ? pp_r224 : 0, plain ? pp_r192 : 0, 1.15, 0.92};
+        for (int c = 0; c < 5; ++c) {
+            if ((geglu && cand[c] != 128) || rate[c] <= 0) continue;
             const long t = mt * ((N + cand[c] - 1) / cand[c]) * S;
             if (t < 192) continue;                                   // would leave a quarter of the CUs idle
             const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
@@ -476,22 +474,25 @@ static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
 
 // MX fp8 operands: 256-row ping-pong tile width (160 / 128) or 0 = keep the 128-row kernel.  Same cost model as gemm_tile with the MX
 // rates (isolated Flux shapes, profiles/mx_probe.py); the quantised-output epilogue needs 64-column wave tiles (BN = 128).
-static int mx_pp_bn(long tiles_m256, long tiles_m128, int N, int K, int S, bool c8, long extra160 = 0, long extra128 = 0, long extra_old = 0) {
+static int mx_pp_bn(long tiles_m256, long tiles_m128, int N, int K, int S, bool c8, long ym256 = 0, long ym128 = 0, int yN = 0) {      // y*: the second problem of a two-problem launch
     static const int pp_policy = getenv("LDX_PP") ? atoi(getenv("LDX_PP")) : 1;
     static const int pp_mink = getenv("LDX_PP_MINK_MX") ? atoi(getenv("LDX_PP_MINK_MX")) : 2048;
     if (!pp_policy || N < 256 || K < pp_mink) return 0;
     double best = 1e30; int best_bn = 0;
-    const int cand[2] = {160, 128};
-    const double rate[2] = {2.0, 1.75};
-    for (int c = 0; c < 2; ++c) {
-        if (c8 && cand[c] != 128) continue;
-        const long t = tiles_m256 * ((N + cand[c] - 1) / cand[c]) * S + (c == 0 ? extra160 : extra128);
+    // per-round rates from the 8192^3 sweep (profiles/ubench/README.md): wider tiles move fewer operand bytes per flop, and N = 3072 fits one round of 224s
+    static const double r224 = getenv("LDX_MX224_RATE") ? atof(getenv("LDX_MX224_RATE")) : 2.08;      // 0: never
+    static const double r192 = getenv("LDX_MX192_RATE") ? atof(getenv("LDX_MX192_RATE")) : 2.1;
+    const int cand[4] = {224, 192, 160, 128};
+    const double rate[4] = {r224, r192, 1.93, 1.75};
+    for (int c = 0; c < 4; ++c) {
+        if ((c8 && cand[c] != 128 && cand[c] != 192) || rate[c] <= 0) continue;
+        const long t = tiles_m256 * ((N + cand[c] - 1) / cand[c]) * S + ym256 * ((yN + cand[c] - 1) / cand[c]);
         if (t < 192) continue;
         const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
         if (cost < best) { best = cost; best_bn = cand[c]; }
     }
     if (!best_bn) return 0;
-    const long to = tiles_m128 * ((N + 127) / 128) * S + extra_old;
+    const long to = tiles_m128 * ((N + 127) / 128) * S + ym128 * ((yN + 127) / 128);
     const double cost_old = (double)((to + 511) / 512) * 512.0 * 128.0 * 128.0 / 1.2;
     return (pp_policy >= 2 || best < 0.95 * cost_old) ? best_bn : 0;
 }
@@ -501,10 +502,9 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     if (MODE == 0 && a.f8) {        // MX fp8 operands: a K-tile holds 128 elements, so the tile heuristics see K / 2
         if constexpr (MODE == 0) {
             static const int force = getenv("LDX_GEMM_TILE") ? atoi(getenv("LDX_GEMM_TILE")) : 0;
-            const int bn = force ? (force / 1000 == 256 ? (a.C8 ? 128 : (force % 1000 == 160 ? 160 : 128)) : 0)
+            const int bn = force ? (force / 1000 == 256 ? (force % 1000 == 192 ? 192 : a.C8 ? 128 : (force % 1000 == 224 ? 224 : force % 1000 == 160 ? 160 : 128)) : 0)
                                  : (a.M >= 1024 ? mx_pp_bn((a.M + 255) / 256, (a.M + 127) / 128, a.N, a.K, S, a.C8 != nullptr) : 0);
-            if (bn == 160) { launch_gemm_pp(a, 160, false, S, DTypeOf<T>::v, s); return; }
-            if (bn == 128) { launch_gemm_pp(a, 128, false, S, DTypeOf<T>::v, s); return; }
+            if (bn) { launch_gemm_pp(a, bn, false, S, DTypeOf<T>::v, s); return; }
         }
         const TileSel t = gemm_tile(a.M, a.N, a.K / 2, a.geglu != 0, S, false);      // no MX ping-pong kernel yet (256 x 128 only when forced)
         if (t.bm == 256 && t.bn == 128) launch_gemm_inst<T, 0, 256, 128, 4, true>(a, S, s);      // opt-in (LDX_TILE256)
@@ -513,7 +513,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
         else launch_gemm_inst<T, 0, 128, 128, 2, true>(a, S, s);
         return;
     }
-    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S);
+    const TileSel t = gemm_tile(a.M, a.N, a.K, a.geglu != 0, S, true, MODE == 0 && !a.ln_c1);
     if constexpr (MODE == 0) {
         if (a.ln_c1) {       // LayerNorm folded in (no split-K): the tile shapes a transformer block's q|k|v / q / GEGLU projections take
             if (t.bm == 256 && t.bn != 128 && !a.geglu) launch_gemm_pp(a, 160, true, 1, DTypeOf<T>::v, s);
@@ -524,8 +524,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
             return;
         }
     }
-    if (t.bm == 256 && t.bn == 256 && !a.geglu) launch_gemm_pp(a, 256, false, S, DTypeOf<T>::v, s);
-    else if (t.bm == 256 && t.bn == 160 && !a.geglu) launch_gemm_pp(a, 160, false, S, DTypeOf<T>::v, s);
+    if (t.bm == 256 && t.bn > 128 && !a.geglu) launch_gemm_pp(a, t.bn, false, S, DTypeOf<T>::v, s);
     else if (t.bm == 256) launch_gemm_pp(a, 128, false, S, DTypeOf<T>::v, s);
     else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
     else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);
@@ -584,9 +583,10 @@ static int gemm2_pp_bn(const GemmArgs& a, const GemmArgs& b) {
     static const int pp_mink = getenv("LDX_PP_MINK") ? atoi(getenv("LDX_PP_MINK")) : 1024;
     if (!pp_policy || a.f8 || b.f8 || a.K < pp_mink || b.K < pp_mink || a.N < 256 || b.N < 256 || a.M + b.M < 1024) return 0;
     double best = 1e30; int best_bn = 0;
-    const int cand[3] = {256, 160, 128};
-    const double rate[3] = {1.35, 1.15, 0.92};
-    for (int c = 0; c < 3; ++c) {
+    const int cand[5] = {256, 224, 192, 160, 128};
+    const double rate[5] = {1.35, pp_r224, pp_r192, 1.15, 0.92};
+    for (int c = 0; c < 5; ++c) {
+        if (rate[c] <= 0) continue;
         const long t = (long)((a.M + 255) / 256) * ((a.N + cand[c] - 1) / cand[c]) + (long)((b.M + 255) / 256) * ((b.N + cand[c] - 1) / cand[c]);
         if (t < 192) continue;
         const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
@@ -604,9 +604,7 @@ void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s)
     GemmArgs x = a, y = b; x.splitk = y.splitk = 1;
     if (x.f8 && y.f8 && x.M + y.M >= 1024 && y.N >= 256) {       // MX: the two streams of a Flux double block / the two halves of linear1
         const bool c8 = x.C8 || y.C8;
-        const long ym256 = (y.M + 255) / 256, ym128 = (y.M + 127) / 128;
-        const int bn = mx_pp_bn((x.M + 255) / 256, (x.M + 127) / 128, x.N, x.K < y.K ? x.K : y.K, 1, c8,
-                                ym256 * ((y.N + 159) / 160), ym256 * ((y.N + 127) / 128), ym128 * ((y.N + 127) / 128));
+        const int bn = mx_pp_bn((x.M + 255) / 256, (x.M + 127) / 128, x.N, x.K < y.K ? x.K : y.K, 1, c8, (y.M + 255) / 256, (y.M + 127) / 128, y.N);
         if (bn) { launch_gemm_pp2(x, y, bn, dt, s); return; }
     }
     if (const int bn = gemm2_pp_bn(x, y)) {

@@ -7,6 +7,10 @@
 
 namespace ldx {
 
+template <typename T> struct DTypeOf;
+template <> struct DTypeOf<__bf16> { static constexpr DType v = DT_BF16; };
+template <> struct DTypeOf<_Float16> { static constexpr DType v = DT_F16; };
+
 constexpr int BK = 64;
 // BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
 // 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("tile", ["256128", "256160", "256256"])
+@pytest.mark.parametrize("tile", ["256128", "256160", "256192", "256224", "256256"])   # 256192 / 256224: plain GEMMs (16-bit and MX fp8); convs and GEGLU fall to 256128
 def test_op_tests_on_forced_pingpong_tiles(ldx_lib, tile):
     env = dict(os.environ, LDX_GEMM_TILE=tile)
     sel = "test_gemm or test_conv3x3 or test_gemm_mx"
