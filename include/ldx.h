@@ -270,6 +270,16 @@ int ldx_op_mx_quant(const void* X, int ldx, int rows, int K, void* Y, int ldy, v
 int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const void* W8, const void* SW, int sw_ld, int M, int N, int K,
                    const float* bias, int act, const void* R, int ldr, void* C, int ldc, float* Cf, int ldcf,
                    void* C8, int ldc8, void* SC, int sc_ld, int dtype, void* stream);
+/* Two independent plain GEMMs C_i = A_i W_i^T + bias_i in ONE launch: the image and text token streams of a Flux double block each
+ * meet their own weights (src/BlackForest/Flux.py:260-340 DoubleStreamBlock img_* / txt_* linears), and a
+ * launch of its own for the 512-row text stream would leave most of the chip idle.  16-bit operands, or MX fp8 operands laid out as for
+ * ldx_op_gemm_mx.  Large pairs run on the 256-row ping-pong tiles. */
+int ldx_op_gemm2(const void* A1, int lda1, const void* W1, int M1, int N1, int K1, const float* bias1, void* C1, int ldc1,
+                 const void* A2, int lda2, const void* W2, int M2, int N2, int K2, const float* bias2, void* C2, int ldc2, int dtype, void* stream);
+int ldx_op_gemm2_mx(const void* A1, int lda1, const void* SA1, int sa_ld1, const void* W1, const void* SW1, int sw_ld1, int M1, int N1, int K1,
+                    const float* bias1, void* C1, int ldc1,
+                    const void* A2, int lda2, const void* SA2, int sa_ld2, const void* W2, const void* SW2, int sw_ld2, int M2, int N2, int K2,
+                    const float* bias2, void* C2, int ldc2, int dtype, void* stream);
 int ldx_op_conv3x3(const void* X, int ldx, const void* W, int B, int Hin, int Win, int Cin, int Cout,
                    int stride, int Hout, int Wout, int resize_to_out, const float* bias,
                    const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,

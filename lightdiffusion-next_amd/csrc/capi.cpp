@@ -346,6 +346,31 @@ int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const voi
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm_mx");
 }
+int ldx_op_gemm2(const void* A1, int lda1, const void* W1, int M1, int N1, int K1, const float* bias1, void* C1, int ldc1,
+                 const void* A2, int lda2, const void* W2, int M2, int N2, int K2, const float* bias2, void* C2, int ldc2, int dtype, void* stream) {
+    if (!A1 || !W1 || !C1 || !A2 || !W2 || !C2 || M1 <= 0 || N1 <= 0 || K1 <= 0 || M2 <= 0 || N2 <= 0 || K2 <= 0 || K1 % 8 || K2 % 8 || lda1 % 8 || lda2 % 8) {
+        set_error("ldx_op_gemm2: bad argument (K % 8, lda % 8)"); return LDX_EINVAL; }
+    GemmArgs a{}, b{};
+    a.A = A1; a.lda = lda1; a.W = W1; a.M = M1; a.N = N1; a.K = K1; a.bias = bias1; a.C = C1; a.ldc = ldc1; a.rows_per_batch = 1;
+    b.A = A2; b.lda = lda2; b.W = W2; b.M = M2; b.N = N2; b.K = K2; b.bias = bias2; b.C = C2; b.ldc = ldc2; b.rows_per_batch = 1;
+    launch_gemm2(a, b, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_gemm2");
+}
+int ldx_op_gemm2_mx(const void* A1, int lda1, const void* SA1, int sa_ld1, const void* W1, const void* SW1, int sw_ld1, int M1, int N1, int K1,
+                    const float* bias1, void* C1, int ldc1,
+                    const void* A2, int lda2, const void* SA2, int sa_ld2, const void* W2, const void* SW2, int sw_ld2, int M2, int N2, int K2,
+                    const float* bias2, void* C2, int ldc2, int dtype, void* stream) {
+    if (!A1 || !W1 || !SA1 || !SW1 || !C1 || !A2 || !W2 || !SA2 || !SW2 || !C2 || M1 <= 0 || N1 <= 0 || K1 <= 0 || M2 <= 0 || N2 <= 0 || K2 <= 0 ||
+        K1 % 128 || K2 % 128 || lda1 % 16 || lda2 % 16 || sa_ld1 < M1 || sw_ld1 < N1 || sa_ld2 < M2 || sw_ld2 < N2) {
+        set_error("ldx_op_gemm2_mx: bad argument (K % 128, lda % 16, sa_ld >= M, sw_ld >= N)"); return LDX_EINVAL; }
+    GemmArgs a{}, b{};
+    a.A = A1; a.lda = lda1; a.W = W1; a.M = M1; a.N = N1; a.K = K1; a.bias = bias1; a.C = C1; a.ldc = ldc1; a.rows_per_batch = 1;
+    a.f8 = 1; a.SA = (const uint32_t*)SA1; a.sa_ld = sa_ld1; a.SW = (const uint32_t*)SW1; a.sw_ld = sw_ld1;
+    b.A = A2; b.lda = lda2; b.W = W2; b.M = M2; b.N = N2; b.K = K2; b.bias = bias2; b.C = C2; b.ldc = ldc2; b.rows_per_batch = 1;
+    b.f8 = 1; b.SA = (const uint32_t*)SA2; b.sa_ld = sa_ld2; b.SW = (const uint32_t*)SW2; b.sw_ld = sw_ld2;
+    launch_gemm2(a, b, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_gemm2_mx");
+}
 int ldx_op_conv3x3(const void* X, int ldx_, const void* W, int B, int Hin, int Win, int Cin, int Cout, int stride, int Hout, int Wout,
                    int resize_to_out, const float* bias, const float* rowvec, int rowvec_ld, const void* R, int ldr, void* Y, int ldy,
                    int dtype, void* stream) {

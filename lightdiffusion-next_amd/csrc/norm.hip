@@ -44,7 +44,26 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GroupNormArgs p, in
         for (int e = 0; e < 8; ++e) { s[k][e] = 0.f; q[k][e] = 0.f; }
 
     if (ty < RY) {
-        for (int pix = pb + ty; pix < pe; pix += RY) {
+        // four pixel rows of loads in flight per thread (one at a time left the kernel latency-bound at ~2.2 TB/s); the sums still take the rows
+        // in the same order as the one-row loop, so the statistics are bit-identical to it
+        int pix = pb + ty;
+        for (; pix + 3 * RY < pe; pix += 4 * RY) {
+            uint4 u[4][CH];
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < CH; ++k) u[r][k] = *(const uint4*)(X + (long)(pix + r * RY) * p.ldx + (tx + TX * k) * 8);
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int k = 0; k < CH; ++k) {
+                    float f[8];
+                    unpack8<T>(u[r][k], f);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) { s[k][e] += f[e]; q[k][e] = fmaf(f[e], f[e], q[k][e]); }
+                }
+        }
+        for (; pix < pe; pix += RY) {
 #pragma unroll
             for (int k = 0; k < CH; ++k) {
                 float f[8];
@@ -119,19 +138,32 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, in
     T* __restrict__ Y = (T*)p.Y + (long)b * p.HW * p.ldy;
     const int per = (p.HW + nblk - 1) / nblk;
     const int pb = blockIdx.x * per, pe = min(p.HW, pb + per);
-    for (int pix = pb + ty; pix < pe; pix += RY) {
+    auto emit = [&](const uint4& u, const int pix, const int k) __attribute__((always_inline)) {
+        float f[8];
+        unpack8<T>(u, f);
 #pragma unroll
-        for (int k = 0; k < CH; ++k) {
-            float f[8];
-            unpack8<T>(*(const uint4*)(X + (long)pix * p.ldx + (tx + TX * k) * 8), f);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                float y = fmaf(f[e], sc[k][e], sh[k][e]);
-                if (p.silu) y = silu_f(y);
-                f[e] = y;
-            }
-            *(uint4*)(Y + (long)pix * p.ldy + (tx + TX * k) * 8) = pack8<T>(f);
+        for (int e = 0; e < 8; ++e) {
+            float y = fmaf(f[e], sc[k][e], sh[k][e]);
+            if (p.silu) y = silu_f(y);
+            f[e] = y;
         }
+        *(uint4*)(Y + (long)pix * p.ldy + (tx + TX * k) * 8) = pack8<T>(f);
+    };
+    int pix = pb + ty;
+    for (; pix + 3 * RY < pe; pix += 4 * RY) {      // four pixel rows of loads in flight per thread
+        uint4 u[4][CH];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) u[r][k] = *(const uint4*)(X + (long)(pix + r * RY) * p.ldx + (tx + TX * k) * 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) emit(u[r][k], pix + r * RY, k);
+    }
+    for (; pix < pe; pix += RY) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) emit(*(const uint4*)(X + (long)pix * p.ldx + (tx + TX * k) * 8), pix, k);
     }
 }
 

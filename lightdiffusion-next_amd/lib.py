@@ -103,6 +103,8 @@ _SIGS = {
     "ldx_op_layernorm_mx": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_attention_mx": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ldx_op_mx_quant": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "ldx_op_gemm2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ldx_op_gemm2_mx": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ldx_op_gemm_mx": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_layernorm": (_i, [_vp, _i, _vp, _i, _i, _i, _f, _vp, _vp, _i, _vp]),
     "ldx_op_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),

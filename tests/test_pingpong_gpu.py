@@ -50,3 +50,22 @@ def test_large_shapes_pick_the_pingpong_kernel_and_match_torch(ldx, ldx_lib):
     ref = torch.nn.functional.conv2d(X.float().permute(0, 3, 1, 2), Wp.float().reshape(Cout, 3, 3, Cin).permute(0, 3, 1, 2), padding=1)
     ref = ref.permute(0, 2, 3, 1).reshape(B * H * H, Cout)
     assert float((Y.float() - ref).norm() / ref.norm()) < 4e-3
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", ["gemm16", "gemm2_16", "gemm_mx", "gemm2_mx"])
+def test_multi_round_and_two_problem_launches(ldx_lib, case, dt):
+    """Launches of more than one round of 256-row tiles (one or two problems per launch, 16-bit or MX fp8 operands, ragged edges, quantised
+    output on the 256 x 192 tile): against torch fp32 / the fp64 product of the dequantised operands."""
+    import torch
+    import _pp_multiround_cases as cases
+    td, code = {"bf16": (torch.bfloat16, 0), "f16": (torch.float16, 1)}[dt]
+    outs, refs = cases.CASES[case](ldx_lib, td, code)
+    torch.cuda.synchronize()
+    for o, r in zip(outs, refs):
+        if o.dtype == torch.uint8:
+            assert torch.equal(o.cpu(), r.cpu()), "quantised output differs from quantising the 16-bit output"
+            continue
+        rel = float((o.double() - r.double()).norm() / r.double().norm())
+        tol = 5e-5 if o.dtype == torch.float32 else (4e-3 if dt == "bf16" else 6e-4)
+        assert rel <= tol, f"{case} {o.dtype}: rel-L2 {rel:.3e}"
