@@ -179,7 +179,24 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs p) {
     const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx + g * cpg;
     T* __restrict__ Y = (T*)p.Y + (long)b * p.HW * p.ldy + g * cpg;
     float su = 0.f, sq = 0.f;
-    for (long i = tid; i < total; i += 256) {
+    long i = tid;
+    for (; i + 3 * 256 < total; i += 4 * 256) {        // four 16-byte loads in flight per thread
+        uint4 u[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long ii = i + r * 256;
+            const int pix = (int)(ii / cpc), ch = (int)(ii % cpc);
+            u[r] = *(const uint4*)(X + (long)pix * p.ldx + ch * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float f[8];
+            unpack8<T>(u[r], f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { su += f[e]; sq = fmaf(f[e], f[e], sq); }
+        }
+    }
+    for (; i < total; i += 256) {
         const int pix = (int)(i / cpc), ch = (int)(i % cpc);
         float f[8];
         unpack8<T>(*(const uint4*)(X + (long)pix * p.ldx + ch * 8), f);
@@ -193,10 +210,9 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs p) {
     const float mean = ((red[0][0] + red[0][1]) + (red[0][2] + red[0][3])) / n;
     const float var = fmaxf(((red[1][0] + red[1][1]) + (red[1][2] + red[1][3])) / n - mean * mean, 0.f);
     const float rstd = rsqrtf(var + p.eps);
-    for (long i = tid; i < total; i += 256) {
-        const int pix = (int)(i / cpc), ch = (int)(i % cpc);
+    auto emit = [&](const uint4& u, const int pix, const int ch) __attribute__((always_inline)) {
         float f[8];
-        unpack8<T>(*(const uint4*)(X + (long)pix * p.ldx + ch * 8), f);
+        unpack8<T>(u, f);
         const float* gm = p.gamma + g * cpg + ch * 8;
         const float* bt = p.beta + g * cpg + ch * 8;
         const float4 g0 = *(const float4*)gm, g1 = *(const float4*)(gm + 4), b0 = *(const float4*)bt, b1 = *(const float4*)(bt + 4);
@@ -209,13 +225,30 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs p) {
             f[e] = y;
         }
         *(uint4*)(Y + (long)pix * p.ldy + ch * 8) = pack8<T>(f);
+    };
+    i = tid;
+    for (; i + 3 * 256 < total; i += 4 * 256) {
+        uint4 u[4]; int px[4], cc[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const long ii = i + r * 256;
+            px[r] = (int)(ii / cpc); cc[r] = (int)(ii % cpc);
+            u[r] = *(const uint4*)(X + (long)px[r] * p.ldx + cc[r] * 8);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) emit(u[r], px[r], cc[r]);
+    }
+    for (; i < total; i += 256) {
+        const int pix = (int)(i / cpc), ch = (int)(i % cpc);
+        emit(*(const uint4*)(X + (long)pix * p.ldx + ch * 8), pix, ch);
     }
 }
 
 template <typename T>
 static void launch_gn_t(const GroupNormArgs& a_in, hipStream_t s) {
     GroupNormArgs a = a_in;
-    if ((a.C / a.G) % 8 == 0 && (long)a.HW * (a.C / a.G) <= 256 * 80 && a.G * a.B >= 32) {
+    static const long small_max = getenv("LDX_GN_SMALL_MAX") ? atol(getenv("LDX_GN_SMALL_MAX")) : 256 * 80;      // elements per (batch, group) the one-launch kernel takes
+    if ((a.C / a.G) % 8 == 0 && (long)a.HW * (a.C / a.G) <= small_max && a.G * a.B >= 32) {
         hipLaunchKernelGGL((gn_small_kernel<T>), dim3(a.G, a.B), dim3(256), 0, s, a);
         return;
     }
