@@ -57,13 +57,15 @@ def attn(B=2, H=8, N=16384, M=None, D=40, reps=10):
     print(f"attn B{B} H{H} N{N} M{M} D{D}: {ms:.3f} ms  {fl / ms / 1e9:.1f} TFLOP/s")
 
 
-def gemm(M=32768, N=320, K=320, reps=20):
+def gemm(M=32768, N=320, K=320, reps=20, geglu=0):
     A = torch.randn(M, K, device="cuda").bfloat16()
     W = torch.randn(N, K, device="cuda").bfloat16()
-    Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
-    fn = lambda: L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, 0, None, 0, p(Cc), N, None, 0, 0, st())
+    No = N // 2 if geglu else N                      # GEGLU: value / gate column pairs -> N / 2 outputs
+    Cc = torch.empty(M, No, device="cuda", dtype=torch.bfloat16)
+    fn = lambda: L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, geglu, None, 0, p(Cc), No, None, 0, 0, st())
+    assert fn() == 0
     ms = timeit(fn, reps)
-    print(f"gemm {M}x{N}x{K}: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    print(f"gemm {M}x{N}x{K}{' geglu' if geglu else ''}: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
 
 
 def conv(B=2, H=128, Cin=320, Cout=320, reps=10):
@@ -103,6 +105,8 @@ if __name__ == "__main__":
         conv(); conv(H=64, Cin=640, Cout=640); conv(H=32, Cin=1280, Cout=1280); conv(H=16, Cin=1280, Cout=1280); conv(H=16, Cin=2560, Cout=1280)
     if what in ("gn", "all"):
         gn(); gn(HW=4096, Cn=640); gn(HW=1024, Cn=1280); gn(HW=256, Cn=2560)
+    if what == "geglu":    # the three GEGLU projections of an SD1.5 step (run with LDX_GEMM_TILE unset / =256128)
+        gemm(32768, 2560, 320, geglu=1); gemm(8192, 5120, 640, geglu=1); gemm(2048, 10240, 1280, geglu=1)
     if what == "ksweep":
         for (M, N) in ((32768, 320), (8192, 640), (2048, 1280)):
             for K in (64, 128, 320, 640, 1280, 2560):
