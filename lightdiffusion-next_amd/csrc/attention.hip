@@ -106,6 +106,7 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
             const int ch = ks * 4 + g4;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));   // wait for Q here, not at the first MFMA inside the loop (see attn32_kernel)
             qf[qt][ks] = as_v8<T>(u);
         }
     }
@@ -307,6 +308,20 @@ __global__ __launch_bounds__(256, 2) void attn_kernel(const AttnArgs p) {
 }
 
 
+// Maximum of the 32 scores a lane holds for one query (two 32x32 S^T tiles): four independent v_max3 chains of depth 4 instead of one
+// serial chain of depth 16 — a wave issues in order, so the serial form exposed ~16 dependent-VALU latencies per query tile and key block.
+__device__ __forceinline__ float max32_tree(const float (&a)[16], const float (&b)[16]) {
+    float m0 = fmaxf(a[0], a[1]), m1 = fmaxf(a[8], a[9]), m2 = fmaxf(b[0], b[1]), m3 = fmaxf(b[8], b[9]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        m0 = fmaxf(fmaxf(m0, a[2 * j]), a[2 * j + 1]);
+        m1 = fmaxf(fmaxf(m1, a[8 + 2 * j]), a[8 + 2 * j + 1]);
+        m2 = fmaxf(fmaxf(m2, b[2 * j]), b[2 * j + 1]);
+        m3 = fmaxf(fmaxf(m3, b[8 + 2 * j]), b[8 + 2 * j + 1]);
+    }
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 32x32x16 variant for 32 < D <= 48 (SD1.5 level 0: D = 40, the largest kernel of a step).  On gfx950 the 16x16x32 MFMA
 // issues every ~21.5 cycles (75 % of peak) while 32x32x16 issues every 32.4 cycles for twice the work (profiles/ubench/
@@ -356,6 +371,9 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
             const int ch = 2 * ks + h2;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));   // consume the load HERE: otherwise hipcc's waitcnt pass, which sees the Q loads still pending on the
+                                                     // nblk == 0 / exec-masked paths around the first lstore, puts the wait at the first QK^T MFMA INSIDE the
+                                                     // loop as vmcnt(0) — right behind the next block's staging loads, whose latency then stalls every iteration
             qf[qt][ks] = as_v8<T>(u);
         }
     }
@@ -463,25 +481,29 @@ __global__ __launch_bounds__(256, 2) void attn32_kernel(const AttnArgs p) {
         }
         // ---- online softmax; P packed as B-operand fragments: k-step st takes registers 8*(st&1)..+7 of key tile st>>1 ----
         V8 pf[2][4];
+        float mcs[2], alphas[2];
 #pragma unroll
-        for (int qt = 0; qt < 2; ++qt) {
-            float mx = sv[0][qt][0];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sv[kt][qt][r]);
+        for (int qt = 0; qt < 2; ++qt) {             // statistics of BOTH query tiles first (independent chains), one rescale branch for the pair
+            float mx = max32_tree(sv[0][qt], sv[1][qt]);
             {   // the other half of the wave holds the other 32 keys of the same query
                 auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             }
             const float mnew = fmaxf(mrun[qt], mx);
-            const float mc = (mnew == -INFINITY) ? 0.f : mnew * c;
-            const float alpha = __builtin_amdgcn_exp2f(mrun[qt] * c - mc);
+            mcs[qt] = (mnew == -INFINITY) ? 0.f : mnew * c;
+            alphas[qt] = __builtin_amdgcn_exp2f(mrun[qt] * c - mcs[qt]);
             mrun[qt] = mnew;
-            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-                o[qt][0] = o[qt][0] * alpha;         // whole-vector scale: no element inserts
-                o[qt][1] = o[qt][1] * alpha;
+        }
+        if (__builtin_amdgcn_ballot_w64(alphas[0] != 1.0f || alphas[1] != 1.0f) != 0) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                o[qt][0] = o[qt][0] * alphas[qt];    // whole-vector scale: no element inserts
+                o[qt][1] = o[qt][1] * alphas[qt];
             }
+        }
+#pragma unroll
+        for (int qt = 0; qt < 2; ++qt) {
+            const float mc = mcs[qt];
 #pragma unroll
             for (int st = 0; st < 4; ++st) {
                 V8 f;
@@ -552,8 +574,27 @@ static void launch_attn32_k(const AttnArgs& a, hipStream_t s) {
     dim3 grid(((a.Nq + 255) / 256) * a.H * a.B);
     hipLaunchKernelGGL((attn32_kernel<T, KVB, KROWB, VROWB, VAR>), grid, dim3(256), lds, s, a);
 }
+#include "attn32ap.inc"
 template <typename T>
 static void launch_attn32(const AttnArgs& a, hipStream_t s) {
+    // 8-wave two-group kernel (round 3, attn32ap.inc) when its 512-query workgroups still fill the chip.  LDX_ATTN32_AP: 0 off, 1 (default) phases
+    // separated by the barriers only (hipcc interleaves the next PV MFMAs with the softmax), 2 strict phases, 3 strict + s_setprio around the MFMAs.
+    // Same box, B2 H8 N16384 D40: attn32_kernel 1.197 ms, strict 1.14-1.21, default 1.12-1.15; step 60.02 -> 61.18 it/s.
+    static const int ap = getenv("LDX_ATTN32_AP") ? atoi(getenv("LDX_ATTN32_AP")) : 1;
+    static const long ap_minwg = getenv("LDX_ATTN32_AP_MINWG") ? atol(getenv("LDX_ATTN32_AP_MINWG")) : 256;
+    if (ap && a.Mk >= 64 && (long)((a.Nq + 511) / 512) * a.H * a.B >= ap_minwg) {
+        switch (ap) {
+            case 2: launch_attn32ap<T, 0>(a, s); break;
+            case 3: launch_attn32ap<T, 1>(a, s); break;
+#ifdef LDX_ATTN_ABLATE                                    // timing ablations (wrong results), profiles/ubench/README.md round 3
+            case 4: launch_attn32ap<T, 4>(a, s); break;       // no MFMAs
+            case 8: launch_attn32ap<T, 8>(a, s); break;       // no softmax
+            case 12: launch_attn32ap<T, 12>(a, s); break;     // neither: staging + barriers + fragment reads
+#endif
+            default: launch_attn32ap<T, 2>(a, s); break;
+        }
+        return;
+    }
     static const int kvb = getenv("LDX_ATTN32_KVB") ? atoi(getenv("LDX_ATTN32_KVB")) : 64;       // experiment switch
     // strides 160 / 160 had 2-way conflicts on every fragment read (SQ_LDS_BANK_CONFLICT 88.1 M -> 21.0 M cycles per launch with 144 / 192;
     // same time at D = 40, which is VALU / MFMA bound)
@@ -612,6 +653,7 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
             const int ch = 2 * ks + h2;
             uint4 u = make_uint4(0, 0, 0, 0);
             if (q < p.Nq && ch < dch) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            asm volatile("" : "+v"(u.x), "+v"(u.y), "+v"(u.z), "+v"(u.w));   // wait for Q here, not at the first MFMA inside the loop (see attn32_kernel)
             qf[qt][ks] = as_v8<T>(u);
         }
     }
@@ -724,11 +766,7 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
         V8 pf[QT][4];
 #pragma unroll
         for (int qt = 0; qt < QT; ++qt) {
-            float mx = sv[0][qt][0];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sv[kt][qt][r]);
+            float mx = max32_tree(sv[0][qt], sv[1][qt]);
             {
                 auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mx), __float_as_uint(mx), false, false);
                 mx = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));

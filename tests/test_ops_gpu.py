@@ -248,10 +248,11 @@ def test_attention(L, ldx, dt, case):
     _check(O_, ref, dt, scale=2.0, what=f"attention {case}")
 
 
-def test_attention_online_softmax_rescale(L, ldx):
+@pytest.mark.parametrize("shape", [(1, 2, 512, 40), (4, 16, 2048, 40)])      # second shape: 256 workgroups of 512 queries -> attn32ap_kernel (round 3)
+def test_attention_online_softmax_rescale(L, ldx, shape):
     """Force the running-max rescale: one key late in the sequence dominates every row (cdna guide rule 26)."""
     td, code = DT["bf16"]
-    B, H, N, D = 1, 2, 512, 40
+    B, H, N, D = shape
     g = torch.Generator(device="cuda").manual_seed(9)
     q = torch.randn(B, N, H * D, device="cuda", generator=g)
     k = torch.randn(B, N, H * D, device="cuda", generator=g)

@@ -69,3 +69,16 @@ def test_multi_round_and_two_problem_launches(ldx_lib, case, dt):
         rel = float((o.double() - r.double()).norm() / r.double().norm())
         tol = 5e-5 if o.dtype == torch.float32 else (4e-3 if dt == "bf16" else 6e-4)
         assert rel <= tol, f"{case} {o.dtype}: rel-L2 {rel:.3e}"
+
+
+@pytest.mark.parametrize("env", [{"LDX_ATTN32_AP": "0"},                                   # the 4-wave attn32_kernel (taken by nothing once the 8-wave kernel is on)
+                                 {"LDX_ATTN32_AP": "2"},                                   # strict phases
+                                 {"LDX_ATTN32_AP": "1", "LDX_ATTN32_AP_MINWG": "1"}])      # the 8-wave kernel on every D = 40 grid incl. one ragged 512-query block
+def test_attention_tests_on_forced_d40_kernels(ldx_lib, env):
+    """The D = 40 attention has three kernels behind one dispatcher (attention.hip launch_attn32); the environment switches are read once per
+    process, so the attention op tests (same torch-fp32 / fp64 references and tolerances) run in a subprocess per variant."""
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_ops_gpu.py", "-k", "test_attention"],
+                       cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    print(tail, r.stderr[-500:])
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
