@@ -29,8 +29,11 @@ Prints ONE JSON line on rank 0 (contract in the task prompt) with extra objects:
   cpu_baseline  the oracle (CPU restatement, kind "port") timed on this host's cores on the HEADLINE workload
                 (1024^2, CFG batch 2, >= 2 evaluations); `reference_cpu` carries the build-container measurement of the
                 reference's own path (tests/golden/unet_full.npz, written by oracle/ref_capture_full.py) — never mixed.
-  secondary     N = 1 only: the reference-default "euler" name (forced multi-scale, samplers.py:180-184) and the
-                end-to-end seconds per image (CLIP encode + 20 steps + VAE decode).
+  secondary     N = 1 only: the reference-default "euler" name (forced multi-scale, samplers.py:180-184), the end-to-end seconds per
+                image (CLIP encode + 20 steps + VAE decode), and SURVEY §8(d) configs 3 / 4 / 5 on the same clock: `config3_shard` (8 latents
+                per GPU, CFG batch 16), `flux_fp8` / `flux_bf16` (Flux.1-dev synthetic, one forward and the 28-step sampling chain),
+                `hiresfix_2048` (bislerp, 10 x euler_ancestral_cfgpp at latent 256^2, VAE decode 2048^2, ESRGAN tile) — each with its own
+                roofline object.  --no-configs skips them (the Flux weights alone take ~1.5 min to build).
 """
 import argparse
 import hashlib
@@ -63,6 +66,7 @@ def parse_args(argv=None):
     ap.add_argument("--batch", type=int, default=1, help="config 2 only: images per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true")
+    ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / 4 / 5 secondary lines (Flux weights take ~1.5 min to build)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet config")
     ap.add_argument("--stub-engine", action="store_true",
@@ -195,6 +199,139 @@ def secondary_lines(ldx, unet, cfg, lat, steps):
     return out
 
 
+def _class_table(rep, nrun):
+    cls = {}
+    for k, v in rep.items():
+        e = cls.setdefault(k.split(" ")[0], {"count": 0, "ms": 0.0, "flops": 0.0})
+        e["count"] += v["count"]; e["ms"] += v["ms"]; e["flops"] += v["flops"]
+    return {k: {"launches": v["count"] // nrun, "ms": round(v["ms"] / nrun, 3), **({"tflops": round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 1)} if v["flops"] > 0 and v["ms"] > 0 else {})}
+            for k, v in sorted(cls.items(), key=lambda kv: -kv[1]["ms"])[:5]}
+
+
+def _roof(flops, ms, peak, unit_note):
+    tf = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None, "of": unit_note}
+
+
+def config3_shard_line(ldx, eng, cfg, lat, steps):
+    """SURVEY config 3's PER-GPU shard on one GPU: 8 latents, CFG batch 16, same loop as the headline (pipeline shape bs = 64 over 8 GPUs)."""
+    pb = 8
+    ms_ = ldx.sampling.ModelSamplingDiscrete()
+    sig = ldx.sampling.calculate_sigmas(ms_, "normal", steps + 2)
+    g = torch.Generator().manual_seed(11)
+    pos, neg = torch.randn([1, 77, cfg.context_dim], generator=g), torch.randn([1, 77, cfg.context_dim], generator=g)
+    x = (torch.randn([pb, 4, lat, lat], generator=g) * torch.sqrt(1.0 + sig[0] ** 2.0)).cuda()
+    model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, pb, lat, lat)
+
+    def run(i0, n):
+        for i in range(i0, i0 + n):
+            du, dc = model(x, sig[i])
+            ldx.sampling._step(0, x, du, dc, 7.0, sig[i], sig[i + 1] - sig[i])
+    run(0, 2); torch.cuda.synchronize()
+    x0 = x.clone(); ts = []
+    for _ in range(3):
+        x.copy_(x0); torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(2, steps); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / steps)
+    ms = 1e3 * statistics.median(ts)
+    info = eng.plan_info()
+    assert torch.isfinite(x).all()
+    return {"workload": f"SD1.5 1024^2, {pb} latents per GPU (CFG batch {2 * pb}) = the per-GPU share of bs 64 over 8 GPUs, sample_euler/normal, {steps} steps x 3 regions (median)",
+            "ms_per_step": round(ms, 2), "image_steps_per_s": round(pb * 1e3 / ms, 2), "step_tflop": round(info["flops"] / 1e12, 2),
+            "roofline": _roof(info["flops"], ms, PEAK_BF16_TFLOPS, "whole step, dense bf16 MFMA peak")}
+
+
+def flux_lines(ldx, steps=28):
+    """BASELINE config 4: Flux.1-dev DiT (19 + 38 blocks, 11.9 B synthetic parameters), 1024^2 (4096 image + 256 text tokens), the reference's
+    Flux sampling chain (pipeline.py:215-277: euler_cfgpp / beta, cfg 1 with a zeroed negative -> both branches evaluated, batch 2, guidance 3.0)
+    for 28 steps, in the MX fp8 mode and in bf16."""
+    cfg = ldx.FluxConfig()
+    spec = ldx.weights.flux_state_dict_spec(cfg)
+    g = torch.Generator().manual_seed(1)
+    sd = {}
+    for k, shp in spec:        # cheap fill: one random block tiled (values do not matter for timing; still random data)
+        n = 1
+        for d in shp:
+            n *= d
+        if k.endswith(".bias"):
+            sd[k] = (0.02 * torch.randn(shp, generator=g)).half()
+        elif k.endswith("scale"):
+            sd[k] = torch.ones(shp).half()
+        else:
+            base = torch.randn(min(n, 1 << 20), generator=g) / (shp[-1] ** 0.5)
+            sd[k] = base.repeat((n + base.numel() - 1) // base.numel())[:n].reshape(shp).half()
+    out = {}
+    pos = (torch.randn(1, 256, 4096, generator=g), torch.randn(1, 768, generator=g))
+    neg = (torch.zeros(1, 256, 4096), torch.zeros(1, 768))
+    x1 = torch.randn(1, 16, 128, 128, device="cuda"); t1 = torch.tensor([0.7], device="cuda"); gd = torch.tensor([3.0], device="cuda")
+    for name, fp8, peak in (("flux_fp8", True, 5000.0), ("flux_bf16", False, PEAK_BF16_TFLOPS)):
+        eng = ldx.FluxEngine(cfg, sd, dtype="bf16", fp8=fp8)
+        for _ in range(2):
+            eng.denoise(x1, t1, pos[0].cuda(), pos[1].cuda(), gd)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5):
+            o = eng.denoise(x1, t1, pos[0].cuda(), pos[1].cuda(), gd)
+        torch.cuda.synchronize(); fwd_ms = 1e3 * (time.perf_counter() - t0) / 5
+        info1 = eng.plan_info()
+        eng.profile(True); eng.denoise(x1, t1, pos[0].cuda(), pos[1].cuda(), gd); torch.cuda.synchronize(); eng.profile(False, reset=False)
+        kern = _class_table(eng.profile_report(), 1)
+        ks = ldx.sampling.FluxKSampler(eng)
+        ts = []
+        for rep in range(2):
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            lat = ks.sample(seed=1, steps=steps, cfg=1, sampler_name="euler_cfgpp", scheduler="beta", positive=pos, negative=neg,
+                            latent_image=torch.zeros(1, 16, 128, 128), guidance=3.0)
+            torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        assert torch.isfinite(lat).all() and torch.isfinite(o).all()
+        out[name] = {"workload": f"Flux.1-dev DiT 19+38 blocks (11.9 B synthetic params), 1024^2 = 4096 image + 256 text tokens, {'MX fp8 (e4m3 + E8M0 per 32)' if fp8 else 'bf16'} linears",
+                     "ms_per_forward_bs1": round(fwd_ms, 2), "forward_tflop": round(info1["flops"] / 1e12, 2),
+                     "sampler": f"FluxKSampler euler_cfgpp/beta, {steps} steps, cfg 1 with a zeroed negative (batch-2 evaluations, second run of 2)",
+                     "sampler_s": round(ts[-1], 3), "it_per_s": round(steps / ts[-1], 3), "launches": info1["launches"], "kernels": kern,
+                     "roofline": _roof(info1["flops"], fwd_ms, peak, f"one batch-1 forward, dense {'fp8' if fp8 else 'bf16'} MFMA peak")}
+        eng.close(); del eng, ks
+        torch.cuda.empty_cache()
+    return out
+
+
+def hiresfix_line(ldx, unet, cfg):
+    """BASELINE config 5 (pipeline.py:346-366): 1024^2 latents -> LatentUpscale bislerp x2 -> 10 steps euler_ancestral_cfgpp / normal at denoise 0.45 on the
+    256^2 latent (CFG batch 2) -> VAE decode 2048^2 (untiled) -> one 512^2 tile through the ESRGAN x4 RRDBNet (the UltimateSDUpscale tile size)."""
+    vcfg = ldx.VAEConfig()
+    vae = ldx.VAEDecoderEngine(vcfg, ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(vcfg), seed=1, dtype=torch.float32), dtype="bf16")
+    ecfg = ldx.ESRGANConfig()
+    esr = ldx.ESRGANEngine(ecfg, ldx.weights.synth_state_dict(ldx.weights.esrgan_state_dict_spec(ecfg), seed=3, dtype=torch.float32), dtype="bf16")
+    ks = ldx.sampling.KSampler(unet)
+    g = torch.Generator().manual_seed(5)
+    pos, neg = torch.randn([1, 77, cfg.context_dim], generator=g), torch.randn([1, 77, cfg.context_dim], generator=g)
+    base = torch.randn([1, 4, 128, 128], generator=g).cuda()
+    tile = torch.rand(1, 512, 512, 3, device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))
+    rs = []
+    for rep in range(3):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        up = ldx.latent_upscale(base, 2048, 2048)
+        torch.cuda.synchronize(); t1 = time.perf_counter()
+        trace = []
+        hi = ks.sample(seed=2, steps=10, cfg=8.0, denoise=0.45, sampler_name="euler_ancestral_cfgpp", scheduler="normal", positive=pos, negative=neg,
+                       latent_image=up, trace=trace)
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        img = vae.decode(hi)
+        torch.cuda.synchronize(); t3 = time.perf_counter()
+        big = esr.forward(tile)
+        torch.cuda.synchronize(); t4 = time.perf_counter()
+        rs.append((t1 - t0, t2 - t1, t3 - t2, t4 - t3, len(trace)))
+    assert torch.isfinite(img).all() and torch.isfinite(big).all()
+    med = lambda i: statistics.median(r[i] for r in rs[1:])
+    nev = rs[-1][4]
+    uinfo, vinfo, einfo = unet.plan_info(), vae.plan_info(), esr.plan_info()
+    ev_ms = 1e3 * med(1) / max(nev, 1)
+    return {"workload": "SD1.5 HiresFix 2048^2: bislerp 128^2 -> 256^2 latent, 10 steps euler_ancestral_cfgpp/normal denoise 0.45 (CFG batch 2), VAE decode 2048^2 untiled, ESRGAN x4 on one 512^2 tile",
+            "bislerp_ms": round(1e3 * med(0), 2), "sampler_ms": round(1e3 * med(1), 1), "unet_evaluations": nev, "ms_per_evaluation": round(ev_ms, 2),
+            "vae_decode_2048_ms": round(1e3 * med(2), 1), "esrgan_tile_ms": round(1e3 * med(3), 1), "total_s": round(med(0) + med(1) + med(2) + med(3), 3),
+            "vae_arena_gib": round(vinfo["arena_bytes"] / 2 ** 30, 2),
+            "roofline": _roof(uinfo["flops"], ev_ms, PEAK_BF16_TFLOPS, "one UNet evaluation at latent 256^2 (84.4 TFLOP), dense bf16 MFMA peak"),
+            "vae_roofline": _roof(vinfo["flops"], 1e3 * med(2), PEAK_BF16_TFLOPS, "VAE decode 2048^2"),
+            "esrgan_roofline": _roof(einfo["flops"], 1e3 * med(3), PEAK_BF16_TFLOPS, "RRDBNet x4, 512^2 tile (flops incl. channel padding)")}
+
+
 # ------------------------------------------------------------------------------------------------------
 def main(argv=None):
     args = parse_args(argv)
@@ -226,6 +363,9 @@ def main(argv=None):
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
 
+    if world > 1:
+        # N ranks build the same 859.5 M synthetic parameters at once: give each its share of the host cores instead of N x all of them
+        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
     import ldx_amd as ldx
     cfg = ldx.UNetConfig.tiny(64, 128) if args.tiny else ldx.UNetConfig.sd15()
     sd = None
@@ -357,20 +497,24 @@ def main(argv=None):
         dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
         dv = rep[dom]
         dom_tflops = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         try:
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))[-1]
-            traffic = json.load(open(tj)).get(dom, {}).get("bytes")      # HBM bytes per launch from the committed PMC passes
+            raw = open(tj, "rb").read()
+            tjd = json.loads(raw)
+            traffic = tjd.get(dom, {}).get("bytes")      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)
+            traffic_src = {"file": os.path.relpath(tj, ROOT), "git_blob_sha1": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
+                           "kernel_in_file": dom in tjd, "collected_for": tjd.get("_meta", {}).get("kernel_build")}
         except Exception:
             traffic = None
         step_ms_gpu = statistics.median(gpu_ms)
         roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic,
+                "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": dv["count"] // nprof, "avg_launch_ms": round(dv["ms"] / dv["count"], 4),
                 "flop_per_launch": round(dv["flops"] / dv["count"] / 1e9, 2),
                 "share_of_step": round(dv["ms"] / tot_ms, 4),
-                "step_tflop": round(info["flops"] / 1e12, 4),
+                "step_tflop": round(info["flops"] / 1e12, 4), "step_ms": round(step_ms_gpu, 3),
                 "step_achieved": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12, 2),
                 "step_frac": round(info["flops"] / (step_ms_gpu * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
                 "kernels": kern}
@@ -378,6 +522,24 @@ def main(argv=None):
     secondary = None
     if rank == 0 and world == 1 and not stub and not args.no_secondary and not args.tiny and args.config == 2 and pb == 1:
         secondary = secondary_lines(ldx, eng, cfg, lat, args.steps)
+        if lat == 128 and not args.no_configs:
+            # SURVEY §8(d) configs 3, 4, 5 on the driver's clock (each guarded: a failure is reported in the line, the headline stays valid)
+            for key, fn in (("config3_shard", lambda: config3_shard_line(ldx, eng, cfg, lat, 10)),
+                            ("hiresfix_2048", lambda: hiresfix_line(ldx, eng, cfg)),
+                            ("flux", lambda: flux_lines(ldx))):
+                t0 = time.perf_counter()
+                try:
+                    r = fn()
+                except Exception as e:          # noqa: BLE001 — reported, not swallowed
+                    r = {"error": repr(e)}
+                if key == "flux" and "error" not in r:
+                    for k2, v2 in r.items():
+                        secondary[k2] = v2
+                    secondary["flux_wall_s"] = round(time.perf_counter() - t0, 1)
+                else:
+                    r["wall_s"] = round(time.perf_counter() - t0, 1)
+                    secondary[key] = r
+                torch.cuda.empty_cache()
 
     cpu = None
     if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline and not args.tiny:
@@ -390,7 +552,8 @@ def main(argv=None):
         its = (world if args.config == 2 else 1) * args.steps / elapsed
         headline = (args.config == 2 and pb == 1 and lat == 128 and not args.tiny and not stub)
         line = {
-            "metric": ("STUB " if stub else "") + "sampler it/s (UNet steps/sec) SD1.5 1024x1024 bs=1 bf16",
+            "metric": ("STUB " if stub else "") + (f"sampler it/s (UNet steps/sec) SD1.5 {lat * 8}x{lat * 8} bs={pb if args.config == 2 else gb} {args.dtype}"
+                                                   + ("" if args.config == 2 else f" (SURVEY config 3: global batch {gb} sharded over {world} GPU(s))")),
             "value": round(its, 3), "unit": "it/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": scaling,
             "vs_baseline": (round(its / 2.8, 3) if (world == 1 and headline) else None), "dtype": args.dtype,
@@ -404,6 +567,7 @@ def main(argv=None):
                        "launches_per_step": info["launches"], "hip_graph": not args.no_graph,
                        "vs_baseline_note": "2.8 it/s = README table, RTX 3060 mobile + Stable-Fast (BASELINE.md §1)"},
             "timing": {"repeats": len(regions_max), "statistic": "median of regions; each region = max over ranks",
+                       "wall_region": "K steps + the final all-gather of the latents + the closing fence (ms_per_step, value); roofline.step_ms is the GPU-event time of the K steps alone",
                        "region_ms_per_step": [round(1000.0 * r / args.steps, 3) for r in regions_max],
                        "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
                        "allgather_ms": round(1000.0 * statistics.median(gathers_max), 3),

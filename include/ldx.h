@@ -137,12 +137,21 @@ int ldx_finalize(ldx_engine* e);
  *   ctx     [B2][M][context_dim] fp32 (c["c_crossattn"]), out_nchw like x_nchw.  */
 int ldx_unet_denoise(ldx_engine* e, const float* x_nchw, const float* sigma, const float* ctx,
                      int B2, int h, int w, int M, float* out_nchw, void* stream);
+/* One CFG evaluation as calc_cond_batch builds it (cond/cond.py:186-226: input_x = cat([x] * 2), timestep = cat([sigma] * 2),
+ * c_crossattn = cat([uncond, cond])): x_nchw [B][C][h][w] is read by BOTH halves of the [uncond x B ; cond x B] batch, sigma is
+ * one host scalar shared by every sample, ctx [2B][M][context_dim], out_nchw [2B][C][h][w].  Same arithmetic as
+ * ldx_unet_denoise on the concatenated inputs (bit-identical); replaces two device copies and a fill per sampler step. */
+int ldx_unet_denoise_cfg(ldx_engine* e, const float* x_nchw, float sigma, const float* ctx,
+                         int B, int h, int w, int M, float* out_nchw, void* stream);
 /* Raw UNetModel1.forward (unet.py:679-770): x (already scaled), integer timesteps given as fp32. */
 int ldx_unet_forward(ldx_engine* e, const float* x_nchw, const float* timesteps, const float* ctx,
                      int B2, int h, int w, int M, float* out_nchw, void* stream);
 /* Number of kernel launches in the current plan, algorithmic FLOPs of one forward at the planned shape
  * (2*MACs of every Linear/Conv + 4*B*H*N*M*D per attention), arena bytes. */
 int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes);
+/* Memory behaviour: an engine keeps the launch plan, arena and captured graph of its CURRENT input shape plus up to four earlier
+ * shapes (the multi-scale samplers and HiresFix alternate between resolutions; Flux plans are per (B, h, w, prompt length)).  Each
+ * cached plan holds its own arena; the cache is trimmed oldest-first to at most 4 entries and LDX_PLAN_CACHE_GIB (default 16) GiB. */
 /* Per-kernel-class timing of subsequent eager forwards with HIP events recorded on the launch stream
  * (used by bench.py for the roofline line).  ldx_profile_report writes a JSON object
  * {"<kernel>": {"count", "ms", "flops", "bytes"}, ...} (algorithmic flops/bytes, summed) into buf.
@@ -171,6 +180,12 @@ int ldx_clip_create(const ldx_clip_config* cfg, int device, ldx_engine** out);
  * (negative counts from the end, e.g. -2 = clip-skip 2; Clip.py:218-236).  Causal mask, no padding mask. */
 int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_layer,
                     float* out_last, float* out_inter, void* stream);
+/* Pooled output: the row of `last` [B][T][hidden] (ldx_clip_encode's out_last) at the first position whose id equals eos_token_id —
+ * position 0 when there is none, as torch's argmax over an all-zero row gives (CLIPTextModel_.forward, CLIPTextModel.py:98-106) —
+ * and, when the optional tensor "text_projection.weight" [hidden][hidden] was loaded, that row times its transpose
+ * (CLIPTextModel.forward, CLIPTextModel.py:130,152-163; fp32).  out_pooled [B][hidden] fp32. */
+int ldx_clip_pooled(ldx_engine* e, const float* last, const int32_t* ids, int B, int T, int eos_token_id,
+                    float* out_pooled, void* stream);
 /* Textual-inversion vectors (SDClipModel.set_up_textual_embeddings, src/SD15/SDClip.py:213-267): rows_host [n][hidden] fp32
  * (HOST pointer) become token ids vocab_size .. vocab_size + n - 1 for the following ldx_clip_encode calls; n = 0 removes
  * them.  Synchronous.  The reference rebuilds its nn.Embedding per forward; the engine keeps one side table instead. */

@@ -104,6 +104,12 @@ int ldx_clip_encode(ldx_engine* e, const int32_t* ids, int B, int T, int inter_l
     return e->impl->run_clip((const int*)ids, B, T, inter_layer, out_last, out_inter, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_clip_pooled(ldx_engine* e, const float* last, const int32_t* ids, int B, int T, int eos_token_id, float* out_pooled, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->clip_pooled(last, (const int*)ids, B, T, eos_token_id, out_pooled, (hipStream_t)stream);
+    GUARD_END
+}
 int ldx_clip_set_extra_embeddings(ldx_engine* e, const float* rows_host, int n) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
@@ -219,6 +225,13 @@ int ldx_unet_denoise(ldx_engine* e, const float* x, const float* sigma, const fl
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise: not a UNet engine"); return LDX_ESTATE; }
     return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream);
+    GUARD_END
+}
+int ldx_unet_denoise_cfg(ldx_engine* e, const float* x, float sigma, const float* ctx, int B, int h, int w, int M, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise_cfg: not a UNet engine"); return LDX_ESTATE; }
+    return e->impl->run_cfg(x, sigma, ctx, B, h, w, M, out, (hipStream_t)stream);
     GUARD_END
 }
 int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {

@@ -111,6 +111,7 @@ Engine::~Engine() {
     (void)hipSetDevice(device);
     for (void* p : dev_allocs) (void)hipFree(p);
     if (arena) (void)hipFree(arena);
+    if (d_sigma_cfg) (void)hipFree(d_sigma_cfg);
     if (graph_exec) (void)hipGraphExecDestroy(graph_exec);
     for (PlanSnap& s : plan_cache) { if (s.arena) (void)hipFree(s.arena); if (s.graph_exec) (void)hipGraphExecDestroy(s.graph_exec); }
     for (hipEvent_t ev : prof_events) (void)hipEventDestroy(ev);
@@ -828,13 +829,17 @@ void Engine::plan_stash() {
     s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.ops = std::move(ops); s.flops = flops; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
-    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den;
+    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB;
     s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
     s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
     s.fb_B = fb_B; s.fb_L = fb_L; s.fb_Lt = fb_Lt; s.fb_C = fb_C; s.fb_a_end = fb_a_end; s.fb_b_end = fb_b_end;
     ops.clear(); arena = nullptr; arena_cap = 0; graph_exec = nullptr; graph_valid = false; warm = false; pB2 = ph = pw = pM = 0;
     plan_cache.push_back(std::move(s));
-    if (plan_cache.size() > 4) {
+    // every cached plan keeps its own arena resident: bound the cache by count (4) AND by bytes (LDX_PLAN_CACHE_GIB, default 16 GiB of
+    // stashed arenas — a Flux plan per prompt length, a 2048^2 VAE plan of several GiB ...); oldest first, the newest entry always stays
+    static const size_t cap_bytes = (size_t)((getenv("LDX_PLAN_CACHE_GIB") ? atof(getenv("LDX_PLAN_CACHE_GIB")) : 16.0) * (double)(1ull << 30));
+    auto cached_bytes = [&]() { size_t b = 0; for (const PlanSnap& c : plan_cache) b += c.arena_cap; return b; };
+    while (plan_cache.size() > 4 || (plan_cache.size() > 1 && cached_bytes() > cap_bytes)) {
         PlanSnap& o = plan_cache.front();
         if (o.arena) (void)hipFree(o.arena);
         if (o.graph_exec) (void)hipGraphExecDestroy(o.graph_exec);
@@ -848,7 +853,7 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc) {
         ops = std::move(s.ops); flops = s.flops; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
-        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den;
+        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB;
         fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
         fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
         fb_B = s.fb_B; fb_L = s.fb_L; fb_Lt = s.fb_Lt; fb_C = s.fb_C; fb_a_end = s.fb_a_end; fb_b_end = s.fb_b_end;
@@ -876,7 +881,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
                 p.x = b_x; p.sigma = b_s; p.B = pB2; p.C = cfg.in_channels; p.H = ph; p.W = pw; p.Cpad = 64;
                 p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
                 p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
-                p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s;
+                p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s; p.xB = b_xB;
                 launch_prep(p, dt, ls);
             } break;
             case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
@@ -884,7 +889,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_GEMM: {
                 launch_gemm(o.g, dt, ls);
                 static const bool dbg_nan = getenv("LDX_DEBUG_NAN") != nullptr;          // debug: first GEMM whose 16-bit output holds a NaN / Inf
-                if (dbg_nan && o.g.C) {
+                if (dbg_nan && o.g.C && !prof_graph) {           // never inside a stream capture (the scan synchronises)
                     (void)hipStreamSynchronize(ls);
                     const int Nout = o.g.geglu ? o.g.N / 2 : o.g.N;
                     std::vector<uint16_t> hb((size_t)o.g.M * o.g.ldc);
@@ -910,7 +915,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_FINISH: {
                 FinishArgs f{};
                 f.eps = d_eps; f.ld = cfg.out_channels; f.x = b_den ? b_x : nullptr; f.sigma = b_s; f.out = b_out;
-                f.B = pB2; f.C = cfg.out_channels; f.HW = ph * pw;
+                f.B = pB2; f.C = cfg.out_channels; f.HW = ph * pw; f.xB = b_xB;
                 launch_finish(f, ls);
             } break;
             case OP_VAEPREP: launch_vae_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, vae_pq, vae_pq ? vae_pq + o.i1 * o.i1 : nullptr, dt, ls); break;
@@ -957,7 +962,22 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
     return LDX_OK;
 }
 
-int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st) {
+int Engine::run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st) {
+    if (B <= 0) { set_error("ldx_unet_denoise_cfg: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    if (sigma_cfg_cap < 2 * B) {
+        HIP_OK(hipStreamSynchronize(st));
+        if (d_sigma_cfg) (void)hipFree(d_sigma_cfg);
+        d_sigma_cfg = nullptr; sigma_cfg_cap = 0;
+        HIP_OK(hipMalloc((void**)&d_sigma_cfg, sizeof(float) * 2 * B));
+        sigma_cfg_cap = 2 * B;
+    }
+    launch_fill_f32(d_sigma_cfg, sigma, 2 * B, st);          // outside the captured graph: the value changes every step
+    return run(x, d_sigma_cfg, ctx, 2 * B, h, w, Mc, out, true, st, B);
+}
+
+int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB) {
+    if (xB < 0 || (xB > 0 && B2 % xB != 0)) { set_error("ldx_unet_*: the batch of x must divide the evaluation batch"); return LDX_EINVAL; }
     if (!finalized) { set_error("ldx_unet_*: engine not finalized"); return LDX_ESTATE; }
     if (!x || !sigma_or_t || !ctx || !out || B2 <= 0 || h <= 0 || w <= 0 || Mc <= 0) { set_error("ldx_unet_*: bad argument"); return LDX_EINVAL; }
     HIP_OK(hipSetDevice(device));
@@ -969,7 +989,10 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
             if (rc) return rc;
         }
     }
-    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise);
+    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB);
+    // a captured graph has its pointers baked in: once a call arrives with other bindings (in ANY mode — the eager path below re-records
+    // g_*), that graph must never be replayed against the new g_* (round 3: a stale graph was replayed after an eager call had moved g_*)
+    if (!same) graph_valid = false;
     if (graph_mode && graph_valid && same) {
         HIP_OK(hipGraphLaunch(graph_exec, st));
         return LDX_OK;
@@ -977,7 +1000,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     // capture only once the same (plan, pointers) have been run eagerly before: the first eager pass
     // also performs the one-time hipFuncSetAttribute calls, which are illegal during capture.
     const bool use_graph = graph_mode && warm && same;
-    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; warm = true;
+    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; warm = true;
     hipStream_t ls = st;
     if (use_graph) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -986,7 +1009,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         ls = cap_stream;
     }
-    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise;
+    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB;
     prof_graph = use_graph;
     { int rc = exec_ops(ls); if (rc) return rc; }
     if (use_graph) {

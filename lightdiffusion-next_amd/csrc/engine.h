@@ -114,7 +114,11 @@ public:
     int load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
     int set_tables(const float* ls, int n, const float* temb, int dim);
     int finalize();
-    int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st);
+    int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB = 0);
+    int clip_pooled(const float* last, const int* ids, int B, int T, int eos_id, float* out, hipStream_t st);
+    // one CFG evaluation: x [B] is read by both halves of the [uncond; cond] batch (cond.py:186-226), sigma is one host scalar for every sample
+    int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st);
+    float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;
     int plan(int B2, int h, int w, int Mc);
     int64_t n_launches() const;
     // per-kernel-class HIP-event profile of subsequent forwards (bench.py roofline leg)
@@ -150,7 +154,7 @@ private:
 
     int exec_ops(hipStream_t ls, size_t op_begin = 0, size_t op_end = (size_t)-1);
     // per-call bindings read by exec_ops
-    const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false;
+    const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false; int b_xB = 0, g_xB = 0;
     const int* b_ids = nullptr; float* b_out2 = nullptr;
     // VAE
     std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
@@ -170,6 +174,7 @@ private:
     // CLIP
     std::vector<ClipLayerW> clip_layers; NormW clip_final_ln; float* clip_tok = nullptr; float* clip_pos = nullptr;
     float* clip_extra = nullptr; int clip_extra_n = 0, clip_extra_cap = 0;     // textual-inversion rows for ids >= vocab_size
+    float* clip_proj = nullptr;                                                // optional text_projection.weight [E][E] fp32 (CLIPTextModel.py:130,152-163)
     int clip_inter_planned = -100;
     LinearW te0, te2, conv_in, conv_out, emb_all;
     NormW out_gn;
@@ -216,7 +221,7 @@ private:
         int B2 = 0, h = 0, w = 0, M = 0; std::vector<Op> ops; double flops = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
-        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false;
+        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0;
         // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
         float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
         void *fb_s0 = nullptr, *fb_s1 = nullptr, *fb_x = nullptr; float *fb_first = nullptr, *fb_res = nullptr, *fb_part = nullptr;

@@ -367,6 +367,11 @@ int Engine::finalize_clip() {
              mk_linear(p + ".mlp.fc2", E, c.intermediate_size, true, L.fc2);
     }
     ok = ok && mk_norm("final_layer_norm", E, clip_final_ln);
+    if (ok && host.count("text_projection.weight")) {          // optional: the pooled output's projection (bias-free Linear)
+        const HostTensor* tp = get("text_projection.weight", {E, E});
+        ok = tp != nullptr;
+        if (ok) { clip_proj = upload32((size_t)E * E, [&](size_t i) { return tp->at(i); }); ok = clip_proj != nullptr; }
+    }
     if (!ok) {
         if (!missing.empty()) { set_error("missing or mis-shaped weight: " + missing); return LDX_EMISSING; }
         set_error(std::string("weight upload failed: ") + hipGetErrorString(hipGetLastError()));
@@ -434,6 +439,16 @@ int Engine::set_clip_extra(const float* rows_host, int n) {
     }
     if (n > 0) HIP_OK(hipMemcpy(clip_extra, rows_host, (size_t)n * E * sizeof(float), hipMemcpyHostToDevice));
     clip_extra_n = n;
+    return LDX_OK;
+}
+
+int Engine::clip_pooled(const float* last, const int* ids, int B, int T, int eos_id, float* out, hipStream_t st) {
+    if (kind != KIND_CLIP || !finalized) { set_error("ldx_clip_pooled: not a finalized CLIP engine"); return LDX_ESTATE; }
+    if (!last || !ids || !out || B <= 0 || T <= 0) { set_error("ldx_clip_pooled: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    launch_clip_pooled(last, ids, B, T, ccfg.hidden_size, eos_id, clip_proj, out, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { set_error(std::string("kernel launch: ") + hipGetErrorString(e)); return LDX_EHIP; }
     return LDX_OK;
 }
 

@@ -149,10 +149,15 @@ struct PrepArgs {
     float* temb_out; float* t_out;   // [B][temb_dim], [B]
     int scale_input;                 // 1: divide by sqrt(sigma^2+1) ; 0: raw (ldx_unet_forward)
     const float* t_in;               // if non-null: timestep indices given directly (no sigma lookup)
+    int xB;                          // batch of x (0 = B): sample b reads x[b % xB] — the [uncond; cond] halves of a CFG evaluation share one latent
 };
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s);
 // finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)
-struct FinishArgs { const float* eps; int ld; const float* x; const float* sigma; float* out; int B, C, HW; };
+struct FinishArgs { const float* eps; int ld; const float* x; const float* sigma; float* out; int B, C, HW; int xB; };       // xB as in PrepArgs
+void launch_fill_f32(float* dst, float v, int n, hipStream_t s);
+// CLIP pooled output: row of last[b] at the first position whose id == eos_id (position 0 if none: torch argmax of an all-zero row),
+// then, if proj != null, out[b] = row @ proj^T (proj [E][E] fp32, row-major [out][in])
+void launch_clip_pooled(const float* last, const int* ids, int B, int T, int E, int eos_id, const float* proj, float* out, hipStream_t s);
 void launch_finish(const FinishArgs& a, hipStream_t s);
 
 // 16-bit <-> fp32 conversion helpers for tests / host plumbing

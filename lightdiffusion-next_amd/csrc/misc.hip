@@ -24,11 +24,12 @@ __global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p) {
         const int pix = (int)(bp % HW), b = (int)(bp / HW);
         float scale = 1.f;
         if (p.scale_input) { const float sg = p.sigma[b]; scale = 1.0f / sqrtf(sg * sg + 1.0f); }
+        const int bx = p.xB > 0 ? b % p.xB : b;
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = ch * 8 + e;
-            f[e] = (c < p.C) ? p.x[((long)b * p.C + c) * HW + pix] * scale : 0.f;
+            f[e] = (c < p.C) ? p.x[((long)bx * p.C + c) * HW + pix] * scale : 0.f;
         }
         *(uint4*)((T*)p.xc + ((long)b * HW + pix) * p.Cpad + ch * 8) = pack8<T>(f);
     }
@@ -83,9 +84,39 @@ __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs p) {
         const long bc = idx / p.HW;
         const int c = (int)(bc % p.C), b = (int)(bc / p.C);
         const float e = p.eps[((long)b * p.HW + pix) * p.ld + c];
-        p.out[idx] = p.x ? (p.x[idx] - e * p.sigma[b]) : e;
+        const long xi = p.xB > 0 ? ((long)(b % p.xB) * p.C + c) * p.HW + pix : idx;
+        p.out[idx] = p.x ? (p.x[xi] - e * p.sigma[b]) : e;
     }
 }
+// CLIPTextModel_.forward's pooled_output (clip/CLIPTextModel.py:98-106) and CLIPTextModel.forward's text_projection (:152-163): one block per sample
+__global__ __launch_bounds__(256) void clip_pooled_kernel(const float* last, const int* ids, int T, int E, int eos_id, const float* proj, float* out) {
+    extern __shared__ float srow[];                  // [E]
+    __shared__ int spos;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) {
+        int pos = 0;
+        for (int t = 0; t < T; ++t) if (ids[(long)b * T + t] == eos_id) { pos = t; break; }
+        spos = pos;
+    }
+    __syncthreads();
+    const float* row = last + ((long)b * T + spos) * E;
+    for (int k = tid; k < E; k += 256) srow[k] = row[k];
+    __syncthreads();
+    for (int n = tid; n < E; n += 256) {
+        float acc;
+        if (proj) {
+            acc = 0.f;
+            const float* w = proj + (long)n * E;
+            for (int k = 0; k < E; ++k) acc = fmaf(srow[k], w[k], acc);
+        } else acc = srow[n];
+        out[(long)b * E + n] = acc;
+    }
+}
+void launch_clip_pooled(const float* last, const int* ids, int B, int T, int E, int eos_id, const float* proj, float* out, hipStream_t s) {
+    hipLaunchKernelGGL(clip_pooled_kernel, dim3(B), dim3(256), E * sizeof(float), s, last, ids, T, E, eos_id, proj, out);
+}
+__global__ void fill_f32_kernel(float* dst, float v, int n) { const int i = blockIdx.x * 64 + threadIdx.x; if (i < n) dst[i] = v; }
+void launch_fill_f32(float* dst, float v, int n, hipStream_t s) { hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, v, n); }
 void launch_finish(const FinishArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.C * a.HW;
     int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;

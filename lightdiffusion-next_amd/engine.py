@@ -106,6 +106,20 @@ class UNetEngine:
         """BaseModel.apply_model (ModelBase.py:72-133): x fp32 [B2,4,h,w], sigma [B2] (values), ctx [B2,M,768]."""
         return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out)
 
+    def denoise_cfg(self, x, sigma: float, ctx, out=None):
+        """One CFG evaluation (calc_cond_batch, cond.py:186-226): x fp32 [B,4,h,w] is read by both halves of the [uncond x B; cond x B]
+        batch, sigma is one scalar, ctx [2B,M,768]; returns [2B,4,h,w].  No torch kernel runs: the broadcast of x and sigma happens in
+        the engine's own boundary kernels (ldx_unet_denoise_cfg)."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(), "x must be a contiguous CUDA fp32 NCHW tensor"
+        b, ch, h, w = x.shape
+        assert ch == self.cfg.in_channels
+        assert ctx.is_cuda and ctx.dtype == torch.float32 and ctx.is_contiguous() and ctx.dim() == 3 and ctx.shape[0] == 2 * b and ctx.shape[2] == self.cfg.context_dim
+        if out is None:
+            out = torch.empty((2 * b, self.cfg.out_channels, h, w), device=x.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_unet_denoise_cfg(self._h, lib.ptr(x), float(sigma), lib.ptr(ctx), b, h, w, ctx.shape[1], lib.ptr(out),
+                                                 lib.current_stream_ptr()), "ldx_unet_denoise_cfg")
+        return out
+
     def forward(self, x, timesteps, ctx, out=None):
         """UNetModel1.forward (unet.py:679-770): integer timesteps (as floats), unscaled input."""
         return self._run(self._lib.ldx_unet_forward, x, timesteps, ctx, out)
@@ -239,12 +253,9 @@ class CLIPTextEngine:
         c.hidden_size, c.num_layers, c.num_heads = cfg.hidden_size, cfg.num_layers, cfg.num_heads
         c.intermediate_size, c.max_positions, c.vocab_size = cfg.intermediate_size, cfg.max_positions, cfg.vocab_size
         lib.check(self._lib.ldx_clip_create(C.byref(c), device, C.byref(self._h)), "ldx_clip_create")
-        _load_state_dict(self._lib, self._h, {k: v for k, v in state_dict.items() if "text_projection" not in k},
-                         strip=("text_model.",))
+        _load_state_dict(self._lib, self._h, state_dict, strip=("text_model.",))       # incl. the optional "text_projection.weight"
         lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
         self._tok_dtype = next(v.dtype for k, v in state_dict.items() if k.endswith("embeddings.token_embedding.weight"))
-        tp = state_dict.get("text_projection.weight")
-        self.text_projection = None if tp is None else tp.float().to(self.device)
 
     def forward(self, tokens, intermediate_output=None):
         """tokens: int tensor [B][T] -> (last [B,T,E] after final LN, intermediate (final-LN'd) or None, pooled)."""
@@ -254,11 +265,11 @@ class CLIPTextEngine:
         inter = torch.empty_like(last) if intermediate_output is not None else None
         lib.check(self._lib.ldx_clip_encode(self._h, lib.ptr(ids), b, t, int(intermediate_output or 0), lib.ptr(last),
                                             lib.ptr(inter), lib.current_stream_ptr()), "ldx_clip_encode")
-        # pooled output: row at argmax(tokens == eos_token_id) (CLIPTextModel.py:98-106; eos id 2 -> position 0 quirk)
-        pos = (ids == self.cfg.eos_token_id).int().argmax(dim=-1)
-        pooled = last[torch.arange(b, device=self.device), pos]
-        if self.text_projection is not None:                   # CLIPTextModel.forward (CLIPTextModel.py:146-150); [B,E] host-side plumbing
-            pooled = pooled @ self.text_projection.t()
+        # pooled output: row at argmax(tokens == eos_token_id) (CLIPTextModel.py:98-106; eos id 2 -> position 0 quirk), then the optional
+        # text_projection (CLIPTextModel.py:152-163) — both inside the engine (ldx_clip_pooled), no torch kernel
+        pooled = torch.empty((b, self.cfg.hidden_size), device=self.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_clip_pooled(self._h, lib.ptr(last), lib.ptr(ids), b, t, int(self.cfg.eos_token_id), lib.ptr(pooled),
+                                            lib.current_stream_ptr()), "ldx_clip_pooled")
         return last, inter, pooled
 
     _extra_rows = 0

@@ -69,13 +69,21 @@ class LdxFluxPatch:
         guidance = c.get("guidance")
         if guidance is None and self.engine.cfg.guidance_embed:
             raise ValueError("LdxFluxPatch: this Flux checkpoint embeds guidance; c['guidance'] is required")
-        for k in ("c_concat", "control"):
+        for k in ("c_concat", "control", "attention_mask"):
             if c.get(k) is not None:
                 raise NotImplementedError(f"LdxFluxPatch: conditioning '{k}' is outside the Flux hot path")
         src_device = x.device
         dev = self.engine.device
         f = lambda t: None if t is None else t.to(dev, torch.float32)
-        out = self.engine.denoise(f(x), f(sigma), f(ctx), f(y), f(guidance))
+        h, w = x.shape[-2:]
+        xin = f(x)
+        if (h | w) & 1:
+            # Flux3.forward pads the latent to the 2x2 patch size with CIRCULAR padding and crops the result (Flux.py:749,775-777 /
+            # util.pad_to_patch_size); the CONST denoised x - out * sigma is elementwise, so pad -> engine -> crop is the same thing
+            xin = torch.nn.functional.pad(xin, (0, w & 1, 0, h & 1), mode="circular")
+        out = self.engine.denoise(xin, f(sigma), f(ctx), f(y), f(guidance))
+        if (h | w) & 1:
+            out = out[:, :, :h, :w].contiguous()
         return out if src_device == dev else out.to(src_device)
 
     def to(self, device):

@@ -69,6 +69,7 @@ _SIGS = {
     "ldx_set_tables": (_i, [_vp, _vp, _i, _vp, _i]),
     "ldx_finalize": (_i, [_vp]),
     "ldx_unet_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_denoise_cfg": (_i, [_vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_plan_info": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ldx_profile": (_i, [_vp, _i, _i]),
@@ -78,6 +79,7 @@ _SIGS = {
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),
     "ldx_clip_encode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _vp]),
+    "ldx_clip_pooled": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_set_extra_embeddings": (_i, [_vp, _vp, _i]),
     "ldx_flux_fbcache": (_i, [_vp, _f]),
     "ldx_flux_set_fp8": (_i, [_vp, _i]),

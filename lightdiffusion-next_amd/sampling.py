@@ -201,6 +201,10 @@ class CFGDenoiser:
         """Returns (denoised_uncond, denoised_cond) views, each [B,4,h,w] fp32."""
         xin, sig, out = self._buffers(x.shape)
         b = self.batch
+        if not self.skip_uncond and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
+            # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg): no torch copy / fill kernels in the loop
+            self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out)
+            return out[:b], out[b:]
         xin[:b].copy_(x)
         if not self.skip_uncond:
             xin[b:].copy_(x)

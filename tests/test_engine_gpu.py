@@ -184,3 +184,44 @@ def test_folded_layernorm_mode_vs_oracle(ldx_lib):
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     print(r.stdout[-2000:], r.stderr[-2000:])
     assert r.returncode == 0 and "FOLD_OK" in r.stdout
+
+
+@pytest.mark.parametrize("dt", ["f16", "bf16"])
+def test_denoise_cfg_equals_denoise_on_the_concatenated_batch(setup, ldx, dt):
+    """ldx_unet_denoise_cfg builds calc_cond_batch's [uncond; cond] batch (cond.py:186-226: cat([x] * 2), cat([sigma] * 2)) inside the
+    engine's boundary kernels: bit-identical to ldx_unet_denoise on the torch-concatenated inputs, for B = 1 and B = 3, eager and graph."""
+    cfg, sd, g, eng = setup
+    e = eng[dt]
+    gen = torch.Generator().manual_seed(77)
+    for B in (1, 3):
+        x = torch.randn([B, 4, 16, 16], generator=gen).cuda()
+        ctx = torch.randn([2 * B, 77, cfg.context_dim], generator=gen).cuda()
+        for sigma in (7.25, 0.31):
+            ref = e.denoise(torch.cat([x, x]), torch.full((2 * B,), sigma), ctx).clone()
+            got = e.denoise_cfg(x, sigma, ctx).clone()
+            assert torch.equal(ref, got), f"B {B} sigma {sigma}: {_rel(got, ref.cpu().numpy()):.3e}"
+    x = torch.randn([1, 4, 16, 16], generator=gen).cuda()
+    ctx = torch.randn([2, 77, cfg.context_dim], generator=gen).cuda()
+    xx = torch.cat([x, x]).contiguous()
+    refs = {sg: e.denoise(xx, torch.full((2,), sg).cuda(), ctx).clone() for sg in (5.0, 1.5)}      # eager references, inputs kept alive
+    e.set_graph_mode(True)
+    try:
+        out = torch.empty([2, 4, 16, 16], device="cuda")
+        for sigma in (5.0, 5.0, 5.0, 1.5, 1.5, 5.0):      # the third call replays the captured graph; the sigma slot is refilled outside it
+            e.denoise_cfg(x, sigma, ctx, out=out)
+            assert torch.equal(out, refs[sigma]), sigma
+    finally:
+        e.set_graph_mode(False)
+
+
+def test_cfg_denoiser_uses_the_engine_side_batch(setup, ldx):
+    """sampling.CFGDenoiser goes through denoise_cfg (no torch copy / fill in the loop) and returns what the copy path returned."""
+    cfg, sd, g, eng = setup
+    e = eng["f16"]
+    gen = torch.Generator().manual_seed(5)
+    pos, neg = torch.randn([1, 77, cfg.context_dim], generator=gen), torch.randn([1, 77, cfg.context_dim], generator=gen)
+    x = torch.randn([2, 4, 16, 16], generator=gen).cuda()
+    den = ldx.sampling.CFGDenoiser(e, pos, neg, 7.0, 2, 16, 16)
+    du, dc = den(x, torch.tensor(3.0))
+    ref = e.denoise(torch.cat([x, x]), torch.full((4,), 3.0), den.ctx)
+    assert torch.equal(torch.cat([du, dc]), ref)

@@ -108,3 +108,31 @@ def test_clip_textual_inversion_vs_reference_golden(ldx, ldx_lib, golden_dir, tm
     pairs = [list(zip(gc["ids_0"][c].tolist(), gc["wts_0"][c].tolist())) for c in range(gc["ids_0"].shape[0])]
     cond, _ = eng.encode_token_weights(pairs, layer_idx=-2)
     assert _rel(cond, gc["cond_tiny_skip-2_0"]) <= tol
+
+
+def test_clip_pooled_and_text_projection_in_engine(ldx):
+    """ldx_clip_pooled: eos-position gather (first eos; position 0 when absent — torch argmax of an all-zero row, CLIPTextModel.py:98-106) and the optional
+    bias-free text_projection (CLIPTextModel.py:130,152-163), against the same two torch lines on the engine's own `last`."""
+    cfg = ldx.CLIPConfig.tiny() if hasattr(ldx.CLIPConfig, "tiny") else ldx.CLIPConfig(hidden_size=64, num_layers=2, num_heads=2, intermediate_size=128)
+    spec = ldx.weights.clip_state_dict_spec(cfg)
+    sd = ldx.weights.synth_state_dict(spec, seed=21)
+    E = cfg.hidden_size
+    gen = torch.Generator().manual_seed(3)
+    proj = torch.randn(E, E, generator=gen) / E ** 0.5
+    ids = torch.randint(0, min(cfg.vocab_size, 40000), (4, 77), generator=gen)
+    ids[0, 10] = cfg.eos_token_id; ids[0, 30] = cfg.eos_token_id      # first of two
+    ids[1, 76] = cfg.eos_token_id                                       # last position
+    ids[2, 0] = cfg.eos_token_id                                        # first position
+    ids[3][ids[3] == cfg.eos_token_id] = 1                              # none -> position 0
+    for with_proj in (False, True):
+        sdp = {k: v for k, v in sd.items() if "text_projection" not in k}      # the synthetic spec carries its own projection
+        if with_proj:
+            sdp["text_projection.weight"] = proj
+        eng = ldx.CLIPTextEngine(cfg, sdp, dtype="f16")
+        last, _, pooled = eng.forward(ids)
+        pos = (ids == cfg.eos_token_id).int().argmax(dim=-1)
+        ref = last.cpu()[torch.arange(4), pos]
+        if with_proj:
+            ref = ref @ proj.t()
+        assert pos.tolist() == [10, 76, 0, 0]
+        assert float((pooled.cpu() - ref).abs().max()) <= 1e-5 * max(1.0, float(ref.abs().max())), float((pooled.cpu() - ref).abs().max())
