@@ -381,8 +381,9 @@ def main(argv=None):
     lat = args.latent
     if args.config == 3:
         gb = args.global_batch
-        assert gb % world == 0, f"config 3: global batch {gb} must divide over {world} ranks"
-        pb, scaling = gb // world, "strong"
+        lo_, hi_ = ldx.parallel.shard_bounds(gb, rank, world)          # uneven batches: the remainder goes to the first ranks
+        pb, scaling = hi_ - lo_, "strong"
+        assert pb > 0, f"config 3: global batch {gb} leaves rank {rank} of {world} without work"
     else:
         pb, gb, scaling = args.batch, world * args.batch, "weak"
     total = args.warmup + args.steps
@@ -561,7 +562,7 @@ def main(argv=None):
             "config": {"workload": f"SD1.5 UNet (859.5M params, synthetic seeded weights) sampler loop, latent "
                                    f"[{pb},4,{lat},{lat}] ({lat * 8}x{lat * 8}) per GPU, CFG batch {2 * pb}, ctx 77x768, sample_euler/normal, "
                                    f"multiscale off; SURVEY config {args.config}: {gb} image(s) in flight over {world} GPU(s)",
-                       "survey_config": args.config, "global_batch": gb, "images_per_gpu": pb,
+                       "survey_config": args.config, "global_batch": gb, "images_per_gpu": (pb if args.config == 2 else -(-gb // world)),
                        "image_steps_per_s": round(gb * args.steps / elapsed, 3),
                        "parallelism": f"batch-shard x{world} (replicated weights, one final all-gather of latents)",
                        "launches_per_step": info["launches"], "hip_graph": not args.no_graph,

@@ -54,3 +54,15 @@ def test_weak_scaling_mode_several_images_per_rank():
 def test_refuses_world_size_mismatch():
     p = _run(["--gpus", "2"], env_extra={"RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1"}, check=False)
     assert p.returncode != 0 and "refusing to mis-report" in p.stderr
+
+
+def test_eight_ranks_config3_even_and_uneven_global_batch():
+    """The north_star's 8-GPU leg as far as a GPU-less box allows: bench.py's own 8-rank launch (gloo), SURVEY config 3 with the global batch
+    drawn once and sharded 8 ways — evenly (64 -> 8 per rank) and unevenly (10 -> 2,2,1,1,1,1,1,1) — must reproduce the single-process latents."""
+    for gb in (64, 10):
+        one = _line(_run(["--gpus", "1", "--config", "3", "--global-batch", str(gb)]))
+        eight = _line(_run(["--gpus", "8", "--config", "3", "--global-batch", str(gb)]))
+        assert eight["n_gpus"] == 8 and eight["timing"]["rccl_ranks"] == 8 and len(eight["timing"]["per_rank_ms_per_step"]) == 8
+        assert eight["config"]["global_batch"] == gb and eight["config"]["images_per_gpu"] == -(-gb // 8) and eight["scaling"] == "strong"
+        assert eight["timing"]["allgather_bytes"] == gb * 4 * 8 * 8 * 4
+        assert one["timing"]["latents_sha256_16"] == eight["timing"]["latents_sha256_16"], gb
