@@ -562,6 +562,25 @@ void Engine::op_gn(const char* name, Act X, Act Y, int B, int HW, const NormW& n
     snprintf(o.klabel, sizeof(o.klabel), "gn_stats+gn_apply");
     ops.push_back(o);
 }
+// SURVEY §8 a10-a11 / VERDICT r2 item 1c: GroupNorm statistics from the producing conv / GEMM epilogue.  A GroupNorm whose input tensor was written by
+// the op right before it (so nothing else touches the shared statistics workspace in between) and whose producer launch can do it
+// (gemm_gn_fuse: no split-K, tile width a multiple of the group width, tiles inside one image) drops its statistics pass — one full read
+// of the activation and one launch.  The sums are still deterministic (fixed order per tile, then per tile row); what is given up is the
+// bit-for-bit equality between different BATCH SIZES (the producer's tile shape, hence the summation order, depends on M).
+void Engine::fuse_gn_stats() {
+    for (size_t i = 1; i < ops.size(); ++i) {
+        if (ops[i].kind != OP_GN || ops[i - 1].kind != OP_GEMM) continue;
+        GemmArgs& g = ops[i - 1].g;
+        GroupNormArgs& n = ops[i].gn;
+        if (g.C != n.X || g.ldc != n.ldx || g.N != n.C || (long)g.M != (long)n.B * n.HW) continue;
+        const int nchunk = gemm_gn_fuse(g, n.HW, n.G, gn_ws_rows);
+        if (!nchunk) continue;
+        g.gn_partial = n.partial;
+        n.stats_chunks = nchunk;
+        ops[i].bytes = 2.0 * 2.0 * (double)n.B * n.HW * n.C;       // read + write (apply only)
+        snprintf(ops[i].klabel, sizeof(ops[i].klabel), "gn_apply(fused stats)");
+    }
+}
 void Engine::op_ln(const char* name, Act X, Act Y, const NormW& n) {
     Op o{}; o.kind = OP_LN; o.name = name;
     LayerNormArgs& l = o.ln;
@@ -693,7 +712,7 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         // fixed small buffers
         const size_t o_temb = a_alloc((size_t)B2 * mc * 4), o_e1 = a_alloc((size_t)B2 * ted * 4), o_e2 = a_alloc((size_t)B2 * ted * 4);
         const size_t o_emb = a_alloc((size_t)B2 * emb_total * 4);
-        gn_ws_off = a_alloc((size_t)B2 * GN_NCHUNK * 32 * 2 * 4);
+        gn_ws_off = a_alloc(gn_ws_bytes(B2, (long)h * w));
         const size_t o_eps = a_alloc((size_t)B2 * h * w * cfg.out_channels * 4);
         auto f32p = [&](size_t off) { return bind ? (float*)((char*)arena + off) : (float*)nullptr; };
         d_temb_out = f32p(o_temb); d_e1 = f32p(o_e1); d_e2 = f32p(o_e2); d_emb_all = f32p(o_emb); d_eps = f32p(o_eps);
@@ -817,6 +836,7 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         }
         { Op o{}; o.kind = OP_FINISH; o.name = "finish"; ops.push_back(o); }
         release(ctx16); release(kvall);
+        fuse_gn_stats();
         if (!bind) { arena_peak_dry = arena_peak; arena = saved_arena; }
     }
     pB2 = B2; ph = h; pw = w; pM = Mc;
@@ -1039,7 +1059,10 @@ std::string Engine::profile_json() const {
 
 int64_t Engine::n_launches() const {
     int64_t n = 0;
-    for (const Op& o : ops) n += (o.kind == OP_GN || o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1)) ? 2 : 1;
+    for (const Op& o : ops) {
+        if (o.kind == OP_GN) n += o.gn.stats_chunks > GN_NCHUNK ? 2 : (o.gn.stats_chunks > 0 ? 1 : 2);      // fold + apply / apply / statistics + apply
+        else n += (o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1)) ? 2 : 1;
+    }
     return n;
 }
 

@@ -153,6 +153,10 @@ private:
     bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
 
     int exec_ops(hipStream_t ls, size_t op_begin = 0, size_t op_end = (size_t)-1);
+    // GroupNorm workspace: gn_ws_rows producer rows per image + GN_FOLD folded rows, x 32 groups x 2 floats (ldx_kernels.h gn_workspace_rows)
+    int gn_ws_rows = 256;
+    size_t gn_ws_bytes(int B, long HWmax) { gn_ws_rows = (int)gn_workspace_rows(HWmax); return (size_t)B * (gn_ws_rows + GN_FOLD) * 32 * 2 * 4; }
+    void fuse_gn_stats();          // post-pass over ops: GroupNorms whose input was just written by a fusable GEMM / conv get their statistics from its epilogue
     // per-call bindings read by exec_ops
     const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false; int b_xB = 0, g_xB = 0;
     const int* b_ids = nullptr; float* b_out2 = nullptr;

@@ -203,7 +203,7 @@ int Engine::plan_vae(int B, int h, int w) {
         }
         void* saved = arena;
         if (pass == 0) arena = nullptr;
-        gn_ws_off = a_alloc((size_t)B * GN_NCHUNK * 32 * 2 * 4);
+        gn_ws_off = a_alloc(gn_ws_bytes(B, (long)h * w * 64));
         int H = h, W = w;
         Act x0 = new_act(B * H * W, 64);
         { Op o{}; o.kind = OP_VAEPREP; o.name = "vae.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = v.z_channels; o.i2 = H * W; o.i3 = 64; ops.push_back(o); }
@@ -234,6 +234,7 @@ int Engine::plan_vae(int B, int h, int w) {
         op_conv("vae.conv_out", t, B, H, W, Cl, conv_out, 1, H, W, Act{}, Act{}, nullptr, 0, pix, v.out_ch);
         release(t);
         { Op o{}; o.kind = OP_CLAMP; o.name = "vae.clamp"; o.p0 = pix; o.i0 = B * H * W * v.out_ch; ops.push_back(o); }
+        fuse_gn_stats();
         if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
     }
     pB2 = B; ph = h; pw = w; pM = 0; vae_plan_mode = 1;
@@ -269,7 +270,7 @@ int Engine::plan_vae_encode(int B, int Hpx, int Wpx) {
         }
         void* saved = arena;
         if (pass == 0) arena = nullptr;
-        gn_ws_off = a_alloc((size_t)B * GN_NCHUNK * 32 * 2 * 4);
+        gn_ws_off = a_alloc(gn_ws_bytes(B, (long)Hpx * Wpx));
         int H = Hpx, W = Wpx;
         Act x0 = new_act(B * H * W, 64);
         { Op o{}; o.kind = OP_PIXPREP; o.name = "vae.enc.prep"; o.p1 = ptr(x0); o.i0 = B; o.i1 = 3; o.i2 = H * W; o.i3 = 64; o.f0 = 2.0f; o.f1 = -1.0f; ops.push_back(o); }
@@ -301,6 +302,7 @@ int Engine::plan_vae_encode(int B, int Hpx, int Wpx) {
         op_conv("vae.enc.conv_out", t, B, H, W, Cl, enc_conv_out, 1, H, W, Act{}, Act{}, nullptr, 0, mom, zc2);
         release(t);
         { Op o{}; o.kind = OP_MOMENTS; o.name = "vae.enc.quant_conv"; o.p0 = mom; o.i0 = B; o.i1 = zc2; o.i2 = H * W; ops.push_back(o); }
+        fuse_gn_stats();
         if (pass == 0) { arena_peak_dry = arena_peak; arena = saved; }
     }
     pB2 = B; ph = Hpx; pw = Wpx; pM = 0; vae_plan_mode = 2;

@@ -338,7 +338,7 @@ __device__ __forceinline__ void gemm_tile_body(const GemmArgs& p, const int bloc
         ln_exchange<MI, BM>(lnacc, (float*)smem, wm * (BM / WM), wn, l15, g4, p.K, p.ln_eps, ln1, ln2);     // the K loop ended with a barrier
         gemm_epilogue<T, BM, BN, WM, MI, NJ, true>(p, acc, m0, n0, wm, wn, l15, g4, split, S, ln1, ln2);
     } else {
-        gemm_epilogue<T, BM, BN, WM, MI, NJ, false, RPRE ? MI * NJ : 1>(p, acc, m0, n0, wm, wn, l15, g4, split, S, nullptr, nullptr, rpre, use_rpre);
+        gemm_epilogue<T, BM, BN, WM, MI, NJ, false, RPRE ? MI * NJ : 1, !F8>(p, acc, m0, n0, wm, wn, l15, g4, split, S, nullptr, nullptr, rpre, use_rpre);
     }
 }
 
@@ -542,6 +542,29 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
         int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, s, a);
     }
+}
+
+// Planner query (GemmArgs::gn_partial): which tile will launch_gemm_mode pick for `a`, and can that tile's epilogue produce the consumer
+// GroupNorm's statistics?  Mirrors launch_gemm_mode's mapping from gemm_tile() to an instantiation.  LDX_GN_FUSE=0 switches the fusion off.
+int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
+    static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
+    if (off || a.f8 || a.C8 || a.geglu || a.ln_c1 || !a.C || G <= 0 || a.N % G || a.N % 4 || HW <= 0 || a.M % HW) return 0;
+    if (a.splitk > 1 && a.ws) return 0;
+    const int cpg = a.N / G;
+    const TileSel t = gemm_tile(a.M, a.N, a.K, false, 1, true, a.mode == 0);
+    int bm, bn;
+    if (t.bm == 256 && t.bn > 128) { bm = 256; bn = t.bn; }
+    else if (t.bm == 256) { bm = 256; bn = 128; }
+    else if (t.bn == 32) { bm = 128; bn = 32; }
+    else if (t.bm == 128 && t.bn == 64) { bm = 128; bn = 64; }
+    else if (t.bm == 64) { bm = 64; bn = 64; }
+    else if (t.bn == 160) { bm = 128; bn = 160; }
+    else { bm = 128; bn = 128; }
+    if (bn > 160 || bn % cpg || HW % bm || (bn / cpg) * 2 > 256) return 0;          // epilogue support (gemm_common.h GNS); groups must not straddle tile columns, tiles must not straddle images
+    const int nchunk = HW / bm;
+    if (nchunk > max_chunks) return 0;
+    a.gn_cpg = cpg; a.gn_G = G; a.gn_hw = HW; a.gn_nchunk = nchunk;
+    return nchunk;
 }
 
 // heuristic shared with the planner: how many K splits for an (M, N, K) problem

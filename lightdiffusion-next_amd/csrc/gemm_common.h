@@ -56,7 +56,7 @@ __device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st,
 // Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
 // LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
-template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, int NR = 1>
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, int NR = 1, bool GNOK = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
                                               const int l15, const int g4, const int split, const int S,
                                               const float* lnm, const float* lnr, const uint2 (&rpre)[NR], const bool use_rpre) {
@@ -121,6 +121,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
     // ---- epilogue: lane holds rows m = .. + l15, 4 consecutive columns n = .. + 4*g4 + r ----
     const T* __restrict__ Rp = (const T*)p.R;
     T* __restrict__ Cp = (T*)p.C;
+    // GroupNorm statistics of the stored tile (GemmArgs::gn_partial).  Compiled in only for tiles up to 160 columns: keeping the rounded outputs in
+    // the accumulator registers makes all of them live through the output stage, which the 192..256-wide ping-pong tiles (128 accumulators, 212 VGPRs)
+    // cannot afford without scratch (gemm_gn_fuse never selects those).
+    constexpr bool GNS = GNOK && NJ <= 5 && !LNF;
+    const bool gn = GNS && p.gn_partial != nullptr;
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + l15;
@@ -156,6 +161,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                     if (Rp)     { float r[4]; unpack4<T>((NR > 1 && use_rpre) ? rpre[NR > 1 ? i * NJ + j : 0] : *(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
                     if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
                                   v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
+                    if constexpr (GNS) if (gn) acc[i][j] = (f32x4){to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};      // the 16-bit values the consumer will read, parked in the (dead) accumulator for the statistics pass below
                     if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);     // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
@@ -205,14 +211,53 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
             }
         }
     }
+    if constexpr (GNS) if (gn) {
+        // per-column sums over the tile's rows: in-lane over i (above), DPP over the 16 lanes that share a column, LDS over the WM wave rows;
+        // then one thread per (group of the tile, statistic) adds its gn_cpg columns in a fixed order -> deterministic, no atomics
+        extern __shared__ __attribute__((aligned(16))) char smem_ep[];
+        float* red = (float*)smem_ep;                   // [WM][BN][2]; the operand tiles are dead (barrier below)
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {                  // one column tile at a time: 8 live sums instead of 8 * NJ
+            float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const bool live = m0 + wm * (BM / WM) + i * 16 + l15 < p.M;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float xr = live ? acc[i][j][r] : 0.f; gs[r] += xr; gq[r] = fmaf(xr, xr, gq[r]); }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gs[r] = row16_sum(gs[r]); gq[r] = row16_sum(gq[r]); }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = wn * (BN / 2) + j * 16 + 4 * g4 + r;
+                    red[(wm * BN + col) * 2 + 0] = gs[r];
+                    red[(wm * BN + col) * 2 + 1] = gq[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int cpg = p.gn_cpg, tid = threadIdx.x;
+        if (tid < (BN / cpg) * 2) {
+            const int gl = tid >> 1, st = tid & 1, nc0 = n0 + gl * cpg;
+            if (nc0 < p.N) {
+                float a = 0.f;
+                for (int w = 0; w < WM; ++w)
+                    for (int c = 0; c < cpg; ++c) a += red[(w * BN + gl * cpg + c) * 2 + st];
+                const int b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) / BM;
+                p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + nc0 / cpg) * 2 + st] = a;
+            }
+        }
+    }
 }
 
-template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false>
+template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, bool GNOK = true>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
                                               const int l15, const int g4, const int split, const int S,
                                               const float* lnm = nullptr, const float* lnr = nullptr) {
     const uint2 none[1] = {make_uint2(0u, 0u)};
-    gemm_epilogue<T, BM, BN, WM, MI, NJ, LNF, 1>(p, acc, m0, n0, wm, wn, l15, g4, split, S, lnm, lnr, none, false);
+    gemm_epilogue<T, BM, BN, WM, MI, NJ, LNF, 1, GNOK>(p, acc, m0, n0, wm, wn, l15, g4, split, S, lnm, lnr, none, false);
 }
 
 }  // namespace ldx

@@ -71,7 +71,15 @@ struct GemmArgs {
     const float* ln_c1; float ln_eps;
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
                                    // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
+    // gn_partial != null: the consumer of C is a GroupNorm over the same [B][gn_hw][N] tensor (gn_cpg channels per group, gn_G groups): every
+    // tile also writes the sum / sum of squares of the 16-bit values it stores, per group, to gn_partial[b][tile row][group][2] with
+    // gn_nchunk tile rows per batch image — GroupNormArgs::partial's layout, so the GroupNorm skips its statistics pass (one full read of the
+    // activation).  Only set by gemm_gn_fuse() below: no split-K / GEGLU / MX output, tile width % gn_cpg == 0, gn_hw % tile height == 0.
+    float* gn_partial; int gn_cpg, gn_G, gn_hw, gn_nchunk;
 };
+// Can launch_gemm(a) produce GroupNorm statistics for a consumer GroupNorm(G groups) over [B][HW][a.N]?  If yes, returns the number of
+// tile rows per batch image (the consumer's chunk count) and fills a.gn_* except gn_partial; 0 = not fusable (the GroupNorm runs its own pass).
+int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks);
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
 // two independent plain GEMMs (mode 0, no split-K / GEGLU, both 16-bit or both MX) as one launch of 128x128 tiles
 void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s);
@@ -121,8 +129,14 @@ struct GroupNormArgs {
     const float* gamma; const float* beta;
     float* partial;                // workspace [B][GN_NCHUNK][G][2]
     int nchunk;                    // pixel chunks actually used (<= GN_NCHUNK), set by the launcher
+    int stats_chunks;              // > 0: the producer's epilogue already wrote `stats_chunks` partial rows per batch (GemmArgs::gn_partial): no statistics
+                                   // pass; more than GN_NCHUNK rows are first folded (fixed order) into partial[B][GN_FOLD][G][2] behind them
 };
 constexpr int GN_NCHUNK = 256;
+constexpr int GN_FOLD = 64;         // fold target: partial rows per batch after folding a long producer list
+constexpr int GN_MAX_PRODUCER_CHUNKS = 32768;      // most partial rows per batch a producer may write (VAE 2048^2: 4 Mi pixels in 128-row tiles)
+// floats of GroupNorm workspace for B images whose largest GroupNorm'ed map has HWmax pixels: producer rows (>= GN_NCHUNK) + the fold target
+static inline size_t gn_workspace_rows(long HWmax) { long r = HWmax / 64; if (r < GN_NCHUNK) r = GN_NCHUNK; if (r > GN_MAX_PRODUCER_CHUNKS) r = GN_MAX_PRODUCER_CHUNKS; return (size_t)r; }
 void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s);
 
 // LayerNorm over the last dim C of [rows][ldx] -> [rows][ldy]

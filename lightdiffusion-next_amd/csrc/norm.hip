@@ -244,9 +244,46 @@ __global__ __launch_bounds__(256) void gn_small_kernel(const GroupNormArgs p) {
     }
 }
 
+// Producer-written statistics (GemmArgs::gn_partial) with more rows than gn_apply wants to fold per workgroup: [B][n_in][G][2] -> [B][GN_FOLD][G][2],
+// each output row the fixed-order sum of a contiguous run of input rows (deterministic).  64 threads = (group, statistic) of G = 32.
+__global__ __launch_bounds__(64) void gn_fold_kernel(const float* in, float* out, int n_in, int G) {
+    const int f = blockIdx.x, b = blockIdx.y, t = threadIdx.x;
+    if (t >= G * 2) return;
+    const int per = (n_in + GN_FOLD - 1) / GN_FOLD;
+    const int lo = f * per, hi = min(n_in, lo + per);
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    int c = lo;
+    for (; c + 3 < hi; c += 4) {            // four loads in flight, summed in row order
+        const float v0 = in[((long)b * n_in + c) * G * 2 + t], v1 = in[((long)b * n_in + c + 1) * G * 2 + t];
+        const float v2 = in[((long)b * n_in + c + 2) * G * 2 + t], v3 = in[((long)b * n_in + c + 3) * G * 2 + t];
+        a0 += v0; a1 += v1; a2 += v2; a3 += v3;
+    }
+    for (; c < hi; ++c) a0 += in[((long)b * n_in + c) * G * 2 + t];
+    out[((long)b * GN_FOLD + f) * G * 2 + t] = (a0 + a1) + (a2 + a3);
+}
+
 template <typename T>
 static void launch_gn_t(const GroupNormArgs& a_in, hipStream_t s) {
     GroupNormArgs a = a_in;
+    if (a.stats_chunks > 0) {           // statistics came with the producer's epilogue: apply only
+        const GnGeom g = gn_geom(a.C);
+        a.nchunk = a.stats_chunks;
+        if (a.stats_chunks > GN_NCHUNK) {
+            float* folded = a.partial + (size_t)a.B * a.stats_chunks * a.G * 2;
+            hipLaunchKernelGGL(gn_fold_kernel, dim3(GN_FOLD, a.B), dim3(64), 0, s, a.partial, folded, a.stats_chunks, a.G);
+            a.partial = folded; a.nchunk = GN_FOLD;
+        }
+        int nblk = (a.HW + g.RY * 8 - 1) / (g.RY * 8);
+        if (nblk > 512) nblk = 512;
+        if (nblk < 1) nblk = 1;
+        dim3 grid2(nblk, a.B);
+        switch (g.CH) {
+            case 1: hipLaunchKernelGGL((gn_apply_kernel<T, 1>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk); break;
+            case 2: hipLaunchKernelGGL((gn_apply_kernel<T, 2>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk); break;
+            default: hipLaunchKernelGGL((gn_apply_kernel<T, 4>), grid2, dim3(256), 0, s, a, g.TX, g.RY, nblk); break;
+        }
+        return;
+    }
     static const long small_max = getenv("LDX_GN_SMALL_MAX") ? atol(getenv("LDX_GN_SMALL_MAX")) : 256 * 80;      // elements per (batch, group) the one-launch kernel takes
     if ((a.C / a.G) % 8 == 0 && (long)a.HW * (a.C / a.G) <= small_max && a.G * a.B >= 32) {
         hipLaunchKernelGGL((gn_small_kernel<T>), dim3(a.G, a.B), dim3(256), 0, s, a);

@@ -159,7 +159,7 @@ def test_fullsize_clip_causality(ldx, ldx_lib):
 
 def test_fullsize_vae_decode_properties(ldx, ldx_lib):
     """VAE decoder at full size (49.5 M synthetic parameters) on a 1024^2 image (latent 128^2): deterministic, per-sample (a batch
-    of two decodes to the two single decodes bit for bit) and inside [0, 1] (process_output clamp, VariationalAE.py:595-597)."""
+    of two decodes to the two single decodes within rounding) and inside [0, 1] (process_output clamp, VariationalAE.py:595-597)."""
     cfg = ldx.VAEConfig()
     sd = ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(cfg), seed=1, dtype=torch.float32)
     vae = ldx.VAEDecoderEngine(cfg, sd, device=0, dtype="bf16")
@@ -171,4 +171,9 @@ def test_fullsize_vae_decode_properties(ldx, ldx_lib):
     assert torch.equal(both, vae.decode(z))
     a = vae.decode(z[:1]).clone()
     b = vae.decode(z[1:]).clone()
-    assert torch.equal(both[0], a[0]) and torch.equal(both[1], b[0])
+    # per-sample path.  Since round 3 the GroupNorm statistics come from the producing conv's epilogue (GemmArgs::gn_partial): their summation
+    # order follows the producer's tile shape, which depends on the batch size, so batch-2 and batch-1 decodes agree to rounding, not bit for bit
+    # (SURVEY §8c states a floating-point tolerance; identical batch sizes stay bit-identical: the assertion above and test_fullsize_batch_independence)
+    ra, rb = _rel(both[0], a[0]), _rel(both[1], b[0])
+    print(f"VAE batch 2 vs single decodes: rel-L2 {ra:.2e} / {rb:.2e}")
+    assert ra <= 5e-3 and rb <= 5e-3
