@@ -619,7 +619,7 @@ static void launch_attn32(const AttnArgs& a, hipStream_t s) {
 #define G32_KROW(NKS) ((NKS) * 32 + 16)
 #define G32_VROW(NDT) (((NDT) & 1) ? (NDT) * 64 : (NDT) * 64 + 64)
 #endif
-template <typename T, int NKS, int NDT, int QT, bool ONES>
+template <typename T, int NKS, int NDT, int QT, bool ONES, bool KPFON = true>
 __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
     constexpr int QW = 32 * QT, QB = 4 * QW;
     constexpr int KROW = G32_KROW(NKS), VROW = G32_VROW(NDT);
@@ -731,7 +731,31 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) s[kt][qt] = zero16;
+        // K fragments run KPF k-steps ahead of the MFMAs that consume them (a ring of KPF x 2 fragments).  Left to itself hipcc sinks every
+        // ds_read_b128 to its first use: read x2 / wait / MFMA / read x2 / wait ... — with one MFMA per fragment (QT = 1) each QK^T MFMA then waits
+        // out most of an LDS round trip (D = 128: 16 MFMAs, 8 exposed waits per key block).
+        constexpr int KPF = (NKS >= 10 ? 2 : (NKS < 4 ? NKS : 4)) * (KPFON ? 1 : 0);
         __builtin_amdgcn_s_setprio(1);
+        if constexpr (KPF > 0) {
+            V8 kfr[KPF][2];
+#pragma unroll
+            for (int d = 0; d < KPF; ++d)
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt) kfr[d][kt] = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * KROW + (2 * d + h2) * 16));
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int ks = 0; ks < NKS; ++ks) {
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int qt = 0; qt < QT; ++qt) s[kt][qt] = mfma32(kfr[ks % KPF][kt], qf[qt][ks], s[kt][qt]);
+                if (ks + KPF < NKS) {
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) kfr[ks % KPF][kt] = as_v8<T>(*(const uint4*)(sK + (kt * 32 + l31) * KROW + (2 * (ks + KPF) + h2) * 16));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
@@ -740,6 +764,7 @@ __global__ __launch_bounds__(256, 2) void attn32g_kernel(const AttnArgs p) {
 #pragma unroll
                 for (int qt = 0; qt < QT; ++qt) s[kt][qt] = mfma32(kf, qf[qt][ks], s[kt][qt]);
             }
+        }
         __builtin_amdgcn_s_setprio(0);
 
         float sv[2][QT][16];
@@ -879,11 +904,18 @@ template <typename T, int NKS, int NDT, int QT, bool ONES>
 static void launch_attn32g(const AttnArgs& a, hipStream_t s) {
     constexpr int KROW = G32_KROW(NKS), VROW = G32_VROW(NDT);
     const size_t lds = 2 * AT_KV * (KROW + VROW);
-    static DevOnce once;
-    set_dyn_lds(once, (const void*)attn32g_kernel<T, NKS, NDT, QT, ONES>, (int)lds);
     constexpr int QB = 128 * QT;
     dim3 grid(((a.Nq + QB - 1) / QB) * a.H * a.B);
-    hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT, ONES>), grid, dim3(256), lds, s, a);
+    static const bool kpf = !(getenv("LDX_ATTN_KPF") && atoi(getenv("LDX_ATTN_KPF")) == 0);      // K fragment prefetch ring (round 3); 0: hipcc's just-in-time reads
+    if (kpf) {
+        static DevOnce once;
+        set_dyn_lds(once, (const void*)attn32g_kernel<T, NKS, NDT, QT, ONES, true>, (int)lds);
+        hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT, ONES, true>), grid, dim3(256), lds, s, a);
+    } else {
+        static DevOnce once;
+        set_dyn_lds(once, (const void*)attn32g_kernel<T, NKS, NDT, QT, ONES, false>, (int)lds);
+        hipLaunchKernelGGL((attn32g_kernel<T, NKS, NDT, QT, ONES, false>), grid, dim3(256), lds, s, a);
+    }
 }
 // head dims served by the generic 32x32x16 kernel (LDX_ATTN32G bit mask 1: D=80, 2: D=160, 4: D=128, 8: D=64).  Default 7: same-box
 // step A/B 54.76 -> 55.34 it/s with D = 80 and 160; D = 128 (Flux, VALU denominator instead of a fifth d tile) 19.6 -> 18.4 ms of

@@ -144,9 +144,13 @@ if __name__ == "__main__":
             print(f"conv B{B} {H}x{H} {Cin}->{Cout} (cold W x{len(Ws)}): {ms * 1000:.1f} us  {2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9:.1f} TFLOP/s  W {Cout * 9 * Cin * 2 / ms / 1e6:.0f} GB/s")
         convg(2, 16, 1280, 1280); convg(2, 16, 2560, 1280); convg(2, 32, 1280, 1280); convg(2, 32, 2560, 1280); convg(2, 32, 1920, 1280); convg(2, 64, 1280, 640)
     if what == "shortk":   # the N = K = C projections of the transformer blocks, hipGraph-timed (run under LDX_GEMM_TILE=... to compare tiles)
-        for (M, N, K) in ((32768, 320, 320), (8192, 640, 640), (2048, 1280, 1280), (32768, 960, 320), (8192, 1920, 640)):
+        for (M, N, K) in ((32768, 320, 320), (8192, 640, 640), (2048, 1280, 1280), (32768, 960, 320), (8192, 1920, 640), (32768, 320, 1280), (8192, 640, 2560), (2048, 1280, 5120),
+                          (2048, 3840, 1280), (512, 1280, 1280), (16384, 512, 512), (4352, 3072, 3072)):
             A = torch.randn(M, K, device="cuda").bfloat16(); W = torch.randn(N, K, device="cuda").bfloat16()
             R = torch.randn(M, N, device="cuda").bfloat16(); Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             fn = lambda: L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, 0, p(R), N, p(Cc), N, None, 0, 0, st())
             ms = timeit_graph(fn, 40)
-            print(f"gemm+residual {M}x{N}x{K}: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  {(M * K + 2 * M * N) * 2 / ms / 1e6:.0f} GB/s")
+            ref = A.float() @ W.float().t() + R.float()
+            fn(); torch.cuda.synchronize()
+            err = float((Cc.float() - ref).norm() / ref.norm())
+            print(f"gemm+residual {M}x{N}x{K}: rel-L2 {err:.1e}  {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  {(M * K + 2 * M * N) * 2 / ms / 1e6:.0f} GB/s")
