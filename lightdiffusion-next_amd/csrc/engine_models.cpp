@@ -177,15 +177,30 @@ void Engine::emit_vae_attn(const VaeAttnW& a, Act X, Act OUT, int B, int H, int 
           g.C = ptr(vt); g.ldc = N; g.splitk = 1;
           oo.flops = 2.0 * C * (double)N * C; snprintf(oo.klabel, sizeof(oo.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
           ops.push_back(oo); flops += oo.flops; (void)wv; }
-        // S[N][N] = q_b k_b^T
-        Act S = new_act(N, N);
-        { LinearW kw; kw.w = ptr(rows(k, b * N, N)); kw.b = nullptr; kw.N = N; kw.K = C;
-          op_gemm("vae.attn.qk", rows(q, b * N, N), kw, S, Act{}); }
-        { Op oo{}; oo.kind = OP_SOFTMAX; oo.name = "vae.attn.softmax"; oo.p1 = ptr(S); oo.i0 = N; oo.i1 = N; oo.i2 = N; oo.f0 = 1.0f / std::sqrt((float)C);
-          oo.bytes = 2.0 * 2.0 * N * (double)N; snprintf(oo.klabel, sizeof(oo.klabel), "softmax_rows"); ops.push_back(oo); }
-        // O_b[N][C] = P[N][N] . V[N][C]  with W = V^T[C][N]
-        { LinearW vw; vw.w = ptr(vt); vw.b = nullptr; vw.N = C; vw.K = N;
-          op_gemm("vae.attn.pv", S, vw, rows(o, b * N, N), Act{}); }
+        // Query rows in chunks of Rc: S_c[Rc][N] = q_c k_b^T, row softmax, O_c = P_c V.  The score matrix is never materialised as a whole
+        // (N x N at 2048^2 is 8 GiB and was the arena's peak; at 4096^2 it would be 128 GiB): one chunk is <= 2 GiB, so a 1024^2 decode still runs
+        // the three launches it always ran and a 2048^2 decode 4 x 3 (measured at 2048^2: one chunk 69.3 ms, 512 MiB chunks 71.9, 128 MiB 72.1; the
+        // arena peak then sits at the 2048^2 x 128-channel conv level, 6.5 GiB instead of 8.45).  LDX_VAE_ATTN_CHUNK_MIB overrides (0 = one chunk).
+        static const long chunk_mib = getenv("LDX_VAE_ATTN_CHUNK_MIB") ? atol(getenv("LDX_VAE_ATTN_CHUNK_MIB")) : 2048;
+        int Rc = N;
+        if (chunk_mib > 0) {
+            long r = (chunk_mib << 20) / ((long)N * 2);
+            r = (r / 256) * 256;
+            if (r < 256) r = 256;
+            if (r < N) Rc = (int)r;
+        }
+        Act S = new_act(Rc, N);
+        for (int r0 = 0; r0 < N; r0 += Rc) {
+            const int nr = std::min(Rc, N - r0);
+            Act Sc = rows(S, 0, nr);
+            { LinearW kw; kw.w = ptr(rows(k, b * N, N)); kw.b = nullptr; kw.N = N; kw.K = C;
+              op_gemm("vae.attn.qk", rows(q, b * N + r0, nr), kw, Sc, Act{}); }
+            { Op oo{}; oo.kind = OP_SOFTMAX; oo.name = "vae.attn.softmax"; oo.p1 = ptr(Sc); oo.i0 = nr; oo.i1 = N; oo.i2 = N; oo.f0 = 1.0f / std::sqrt((float)C);
+              oo.bytes = 2.0 * 2.0 * nr * (double)N; snprintf(oo.klabel, sizeof(oo.klabel), "softmax_rows"); ops.push_back(oo); }
+            // O_c[nr][C] = P_c[nr][N] . V[N][C]  with W = V^T[C][N]
+            { LinearW vw; vw.w = ptr(vt); vw.b = nullptr; vw.N = C; vw.K = N;
+              op_gemm("vae.attn.pv", Sc, vw, rows(o, b * N + r0, nr), Act{}); }
+        }
         release(S); release(vt);
     }
     release(q); release(k); release(hn);
