@@ -164,27 +164,31 @@ def _lcm_pad_contexts(conds):
 
 
 class CFGDenoiser:
-    """CFGGuider.predict_noise -> sampling_function -> calc_cond_batch -> wrapper hook
-    (CFG.py:86-234, cond.py:150-288) for one positive and one negative full-area prompt.
+    """CFGGuider.predict_noise -> sampling_function -> calc_cond_batch -> wrapper hook (CFG.py:86-234, cond.py:150-288).
 
-    Batch order is [uncond x B ; cond x B] (cond_or_uncond == [1, 0], cond.py:194-195)."""
+    positive / negative: one full-area context tensor [1 or B, M, C] each, or a LIST of them (several conditioning entries per side).
+    calc_cond_batch runs every entry of both sides in ONE batch, entries in reversed order and the uncond side first
+    ([neg_last .. neg_0, pos_last .. pos_0] x B; cond_or_uncond == [1, .., 0, ..], cond.py:186-195), every context repeated to the lcm of the
+    lengths (cond.py:100-126), and gives each side the mean of its entries' outputs (full area, multiplier 1: ksampler_util.py:106-149 of this
+    snapshot; start_percent / end_percent are computed by calculate_start_end_timesteps but never consulted, so they are not mirrored).
+    With one entry per side this is the [uncond x B ; cond x B] batch of ldx_unet_denoise_cfg."""
 
     def __init__(self, engine, positive, negative, cfg, batch, h, w, disable_cfg1_optimization=False):
         self.engine, self.cfg = engine, float(cfg)
         dev = engine.device
         self.skip_uncond = math.isclose(self.cfg, 1.0) and not disable_cfg1_optimization
-        pos = positive.to(dev, torch.float32)
-        neg = negative.to(dev, torch.float32)
-        pos = pos.expand(batch, -1, -1) if pos.shape[0] == 1 else pos
-        neg = neg.expand(batch, -1, -1) if neg.shape[0] == 1 else neg
-        if self.skip_uncond:
-            self.ctx = pos.contiguous()
-            self.nb = batch
-        else:
-            neg, pos = _lcm_pad_contexts([neg, pos])
-            self.ctx = torch.cat([neg, pos]).contiguous()
-            self.nb = 2 * batch
+        as_list = lambda c: list(c) if isinstance(c, (list, tuple)) else [c]
+        ex = lambda c: (c.to(dev, torch.float32).expand(batch, -1, -1) if c.shape[0] == 1 else c.to(dev, torch.float32))
+        pos, neg = [ex(c) for c in as_list(positive)], [ex(c) for c in as_list(negative)]
+        sides = ([] if self.skip_uncond else [1] * len(neg)) + [0] * len(pos)
+        ctxs = ([] if self.skip_uncond else list(reversed(neg))) + list(reversed(pos))
+        ctxs = _lcm_pad_contexts(ctxs)
+        self.ctx = torch.cat(ctxs).contiguous()
+        self.sides = sides                                  # cond_or_uncond of the batch
+        self.n_entries = len(sides)
+        self.nb = self.n_entries * batch
         self.batch = batch
+        self.simple = (not self.skip_uncond) and sides == [1, 0]
         self._bufs = {}
 
     def _buffers(self, shape):
@@ -197,22 +201,33 @@ class CFGDenoiser:
                                torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32))
         return self._bufs[key]
 
+    def _side(self, out, side):
+        """calc_cond_batch's accumulation for one side: sum of the entries' outputs in batch order / count (cond.py:262-288)."""
+        b = self.batch
+        idx = [i for i, s in enumerate(self.sides) if s == side]
+        if len(idx) == 1:
+            return out[idx[0] * b:(idx[0] + 1) * b]
+        acc = torch.zeros_like(out[:b])
+        for i in idx:
+            acc += out[i * b:(i + 1) * b]
+        return acc / (float(len(idx)) + 1e-37)
+
     def __call__(self, x, sigma):
-        """Returns (denoised_uncond, denoised_cond) views, each [B,4,h,w] fp32."""
+        """Returns (denoised_uncond, denoised_cond), each [B,4,h,w] fp32."""
         xin, sig, out = self._buffers(x.shape)
         b = self.batch
-        if not self.skip_uncond and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
+        if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
             # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg): no torch copy / fill kernels in the loop
             self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out)
             return out[:b], out[b:]
-        xin[:b].copy_(x)
-        if not self.skip_uncond:
-            xin[b:].copy_(x)
+        for i in range(self.n_entries):                     # the general case (cfg 1 / several entries per side): host-side batch assembly
+            xin[i * b:(i + 1) * b].copy_(x)
         sig.fill_(float(sigma))
         self.engine.denoise(xin, sig, self.ctx, out=out)
+        cond = self._side(out, 0)
         if self.skip_uncond:
-            return out, out
-        return out[:b], out[b:]
+            return cond, cond
+        return self._side(out, 1), cond
 
 
 def _step(kind, x, du, dc, cfg, c0, c1, denoised_out=None):
@@ -509,7 +524,7 @@ def _resolve_sampler(sampler_name):
 
 class KSampler:
     """KSampler.sample -> common_ksampler -> sample1 -> CFGGuider.sample (sampling.py:773-1233, CFG.py:164-357)
-    for txt2img / img2img latents with one positive and one negative prompt."""
+    for txt2img / img2img latents; positive / negative are one full-area context each or lists of them (CFGDenoiser)."""
 
     def __init__(self, engine):
         self.engine = engine

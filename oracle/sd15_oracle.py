@@ -257,9 +257,41 @@ def lcm_pad(conds):
     return [c.repeat(1, target // c.shape[1], 1) if c.shape[1] < target else c for c in conds]
 
 
+def _side_mean(outs):
+    """calc_cond_batch's accumulation for full-area entries (cond.py:262-288): out += output * 1, count += 1, out /= count
+    (count starts at 1e-37, which fp32 absorbs): the plain mean of the side's entries, summed in BATCH order."""
+    acc = torch.zeros_like(outs[0])
+    cnt = torch.ones_like(outs[0]) * 1e-37
+    for o in outs:
+        acc = acc + o
+        cnt = cnt + 1.0
+    return acc / cnt
+
+
+def cfg_denoise_multi(denoiser, x, sigma, positives, negatives, cfg, disable_cfg1_optimization=False):
+    """calc_cond_batch with SEVERAL conditioning entries per side (cond.py:150-288; get_area_and_mult of this snapshot gives every entry the
+    full area and multiplier 1, ksampler_util.py:106-149): to_run = positives then negatives, batched in REVERSED order (cond.py:186-194:
+    [neg_last .. neg_0, pos_last .. pos_0]), contexts padded to the lcm of all lengths (cond_cat), each side = the mean of its entries."""
+    b = x.shape[0]
+    ex = lambda c: c.expand(b, -1, -1) if c.shape[0] == 1 else c
+    skip_uncond = math.isclose(cfg, 1.0) and not disable_cfg1_optimization
+    entries = ([] if skip_uncond else [(ex(c), 1) for c in reversed(negatives)]) + [(ex(c), 0) for c in reversed(positives)]
+    ctxs = lcm_pad([e[0] for e in entries])
+    n = len(entries)
+    out = denoiser(torch.cat([x] * n), sigma * x.new_ones([n * b]), torch.cat(ctxs)).chunk(n)
+    cond = _side_mean([o for o, e in zip(out, entries) if e[1] == 0])
+    if skip_uncond or math.isclose(cfg, 1.0):
+        return cond
+    uncond = _side_mean([o for o, e in zip(out, entries) if e[1] == 1])
+    return torch.lerp(uncond, cond, cfg)
+
+
 def cfg_denoise(denoiser, x, sigma, positive, negative, cfg, disable_cfg1_optimization=False):
     """sampling_function + calc_cond_batch + cfg_function (CFG.py:6-161, cond.py:150-288): one batched call
-    in [uncond; cond] order; torch.lerp for the combine."""
+    in [uncond; cond] order; torch.lerp for the combine.  positive / negative: one context tensor, or a list of them (several entries per side)."""
+    if isinstance(positive, (list, tuple)) or isinstance(negative, (list, tuple)):
+        as_list = lambda c: list(c) if isinstance(c, (list, tuple)) else [c]
+        return cfg_denoise_multi(denoiser, x, sigma, as_list(positive), as_list(negative), cfg, disable_cfg1_optimization)
     b = x.shape[0]
     pos = positive.expand(b, -1, -1) if positive.shape[0] == 1 else positive
     if math.isclose(cfg, 1.0) and not disable_cfg1_optimization:

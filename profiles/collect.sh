@@ -6,7 +6,7 @@ ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-graph > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats -d $OUT -o bench --output-format csv -- python $ROOT/bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-secondary --no-graph > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 python $ROOT/profiles/analyze_trace.py $OUT/bench_kernel_trace.csv 30 > $OUT/forward_breakdown.txt 2>&1
 rm -f $OUT/bench_kernel_trace.csv        # large; the stats + breakdown are what is kept
 for what in attn1 conv1 gemm1; do

@@ -23,7 +23,7 @@ print(sys.argv[1], {k: round(v / max(len(disp[k]), 1), 2) for k, v in acc.items(
 PY
   done
 }
-run "attention D=40 B2 H8 N16384 (attn32_kernel)" attn32_kernel python $ROOT/profiles/kprobe.py attn1
+run "attention D=40 B2 H8 N16384 (attn32ap_kernel, 8-wave two-group)" attn32ap_kernel python $ROOT/profiles/kprobe.py attn1
 run "conv3x3 128^2 320->320 (gemm_pp_kernel MODE 1, 256x160 ping-pong tile)" gemm_pp_kernel python $ROOT/profiles/kprobe.py conv1
 run "gemm bf16 8192^3 (gemm_pp_kernel MODE 0, 256x256 ping-pong tile)" gemm_pp_kernel python $ROOT/profiles/kprobe.py gemm1
 run "MX fp8 GEMMs of profiles/mx_probe.py (gemm_pp_kernel<.., F8 = true>)" gemm_pp_kernel python $ROOT/profiles/mx_probe.py 2

@@ -225,3 +225,25 @@ def test_cfg_denoiser_uses_the_engine_side_batch(setup, ldx):
     du, dc = den(x, torch.tensor(3.0))
     ref = e.denoise(torch.cat([x, x]), torch.full((4,), 3.0), den.ctx)
     assert torch.equal(torch.cat([du, dc]), ref)
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_ksampler_several_entries_per_side_vs_reference(setup, ldx, golden_dir, dt, tol):
+    """calc_cond_batch with two positive and two negative conditioning entries (77 / 154 and 77 / 231 tokens -> lcm 462, entries batched in reversed
+    order, each side the mean of its entries; cond.py:150-288): the stand-alone KSampler on the engine vs the reference's latents
+    (oracle/ref_capture_multicond.py).  cfg 1 drops the uncond side (cfg1 optimisation), dpmpp_2m_cfgpp keeps it."""
+    cfg, sd, g0, eng = setup
+    g = np.load(os.path.join(golden_dir, "multicond.npz"))
+    pos = [torch.from_numpy(g["P0"]), torch.from_numpy(g["P1"])]
+    neg = [torch.from_numpy(g["N0"]), torch.from_numpy(g["N1"])]
+    ks = ldx.sampling.KSampler(eng[dt])
+    den = ldx.sampling.CFGDenoiser(eng[dt], pos, neg, 7.0, 2, 16, 16)
+    assert den.sides == [1, 1, 0, 0] and tuple(den.ctx.shape) == (8, 462, 128)
+    assert np.array_equal(den.ctx.cpu()[:, ::33, :4].numpy(), g["hook_euler_ctx_sub"])        # batch order and lcm padding as the reference's hook saw them
+    for name, kw in (("euler", dict(sampler_name="sample_euler", scheduler="normal", cfg=7.0)),
+                     ("euler_cfg1", dict(sampler_name="sample_euler", scheduler="normal", cfg=1.0)),
+                     ("dpmpp2m", dict(sampler_name="dpmpp_2m_cfgpp", scheduler="karras", cfg=5.0))):
+        out = ks.sample(seed=5, steps=4, positive=pos, negative=neg, latent_image=torch.zeros(2, 4, 16, 16), enable_multiscale=False, **kw)
+        r = _rel(out, g[f"ks_{name}"])
+        print(f"[{dt}] multi-entry conds, {name}: rel-L2 {r:.3e}")
+        assert r <= tol
