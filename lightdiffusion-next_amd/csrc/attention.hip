@@ -322,6 +322,18 @@ __device__ __forceinline__ float max32_tree(const float (&a)[16], const float (&
     return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
 }
 
+__device__ __forceinline__ float max32_tree_v(const f32x16& a, const f32x16& b) {       // same tree on the accumulator vectors themselves
+    float m0 = fmaxf(a[0], a[1]), m1 = fmaxf(a[8], a[9]), m2 = fmaxf(b[0], b[1]), m3 = fmaxf(b[8], b[9]);
+#pragma unroll
+    for (int j = 1; j < 4; ++j) {
+        m0 = fmaxf(fmaxf(m0, a[2 * j]), a[2 * j + 1]);
+        m1 = fmaxf(fmaxf(m1, a[8 + 2 * j]), a[8 + 2 * j + 1]);
+        m2 = fmaxf(fmaxf(m2, b[2 * j]), b[2 * j + 1]);
+        m3 = fmaxf(fmaxf(m3, b[8 + 2 * j]), b[8 + 2 * j + 1]);
+    }
+    return fmaxf(fmaxf(m0, m1), fmaxf(m2, m3));
+}
+
 // ------------------------------------------------------------------------------------------------------------
 // 32x32x16 variant for 32 < D <= 48 (SD1.5 level 0: D = 40, the largest kernel of a step).  On gfx950 the 16x16x32 MFMA
 // issues every ~21.5 cycles (75 % of peak) while 32x32x16 issues every 32.4 cycles for twice the work (profiles/ubench/
@@ -586,10 +598,13 @@ static void launch_attn32(const AttnArgs& a, hipStream_t s) {
         switch (ap) {
             case 2: launch_attn32ap<T, 0>(a, s); break;
             case 3: launch_attn32ap<T, 1>(a, s); break;
-#ifdef LDX_ATTN_ABLATE                                    // timing ablations (wrong results), profiles/ubench/README.md round 3
+#ifdef LDX_ATTN_ABLATE                                    // measured-and-not-adopted variants (6, 7: correct, bit-identical) and timing ablations
+            case 6: launch_attn32ap<T, 66>(a, s); break;      // (wrong results) of profiles/ubench/README.md round 3.  6: split softmax (VAR & 64), +6 %
+            case 7: launch_attn32ap<T, 130>(a, s); break;     // 7: K fragments read a phase early (VAR & 128), +-0.5 %
             case 4: launch_attn32ap<T, 4>(a, s); break;       // no MFMAs
             case 8: launch_attn32ap<T, 8>(a, s); break;       // no softmax
             case 12: launch_attn32ap<T, 12>(a, s); break;     // neither: staging + barriers + fragment reads
+            case 34: launch_attn32ap<T, 34>(a, s); break;     // default schedule without the 64 fma of exp2(s * c - m * c)
 #endif
             default: launch_attn32ap<T, 2>(a, s); break;
         }
