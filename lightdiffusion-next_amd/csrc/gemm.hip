@@ -412,6 +412,91 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
     }
 }
 
+// Split-K reduce that also produces the consumer GroupNorm's statistics (GemmArgs::gn_partial with splitk > 1): one workgroup per chunk of
+// gn_hw / gn_nchunk rows of one image x ALL columns.  Thread (rl, quad) owns 4 fixed columns and every R-th row of the chunk, so its sums of the
+// rounded outputs are per column; LDS [R][N][2]; then one thread per (group, statistic) adds its gn_cpg columns over the R row lanes in a
+// fixed order (deterministic, no atomics).  Same partial layout as the GEMM epilogue's: gn_partial[b][chunk][G][2].
+template <typename T>
+__global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const GemmArgs p, const int R) {
+    extern __shared__ float red_gn[];
+    const int nq = p.N >> 2, tid = threadIdx.x;
+    const int rl = tid / nq, n = (tid - rl * nq) * 4;
+    const int RB = p.gn_hw / p.gn_nchunk;
+    const int b = blockIdx.y, chunk = blockIdx.x;
+    const long row0 = (long)b * p.gn_hw + (long)chunk * RB;
+    const T* __restrict__ Rp = (const T*)p.R;
+    T* __restrict__ Cp = (T*)p.C;
+    const size_t stride = (size_t)p.M * p.N;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+    if (rl < R) {
+        constexpr int U = 4;                    // rows in flight per thread (the partial loads of U rows are issued together)
+        for (int r = rl; r < RB; r += R * U) {
+            float v[U][4];
+            bool live[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) { live[u] = r + u * R < RB; v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f; }
+            for (int sidx = 0; sidx < p.splitk; ++sidx) {
+                float4 t[U];
+#pragma unroll
+                for (int u = 0; u < U; ++u) t[u] = live[u] ? *(const float4*)(p.ws + (size_t)sidx * stride + (size_t)(row0 + r + u * R) * p.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int u = 0; u < U; ++u) { v[u][0] += t[u].x; v[u][1] += t[u].y; v[u][2] += t[u].z; v[u][3] += t[u].w; }
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (!live[u]) continue;
+                const long m = row0 + r + u * R;
+                const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    float x = v[u][c];
+                    if (p.bias) x += p.bias[n + c];
+                    if (rv) x += rv[n + c];
+                    if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+                    else if (p.act == 2) x = gelu_tanh_f(x);
+                    else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+                    if (p.gate) x *= p.gate[(long)(m / p.rows_per_batch) * p.gate_ld + n + c];
+                    if (p.oscale != 0.f) x *= p.oscale;
+                    if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + c]);
+                    if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + c]));
+                    v[u][c] = x;
+                    const float xr = to_f32(from_f32<T>(x));      // statistics of the values as stored
+                    gs[c] += xr; gq[c] = fmaf(xr, xr, gq[c]);
+                }
+                *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[u][0], v[u][1], v[u][2], v[u][3]);
+                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) { red_gn[((long)rl * p.N + n + c) * 2] = gs[c]; red_gn[((long)rl * p.N + n + c) * 2 + 1] = gq[c]; }
+    }
+    __syncthreads();
+    if (tid < p.gn_G * 2) {
+        const int g = tid >> 1, st = tid & 1, c0 = g * p.gn_cpg;
+        float a = 0.f;
+        for (int l = 0; l < R; ++l)
+            for (int c = 0; c < p.gn_cpg; ++c) a += red_gn[((long)l * p.N + c0 + c) * 2 + st];
+        p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + g) * 2 + st] = a;
+    }
+}
+// geometry of that launch: R row lanes of N / 4 threads (<= 512 threads, >= 2 * G), chunks of RB rows; 0 = not applicable
+static int splitk_gn_geom(const GemmArgs& a, int HW, int G, int max_chunks, int* R_out) {
+    if (a.N % 4 || !a.C || a.N % G || HW <= 0 || a.M % HW) return 0;
+    const int nq = a.N / 4;
+    if (nq > 512 || nq < 1) return 0;
+    int R = nq <= 128 ? 4 : (nq <= 256 ? 2 : 1);        // a power of two (chunks of R rows must tile the image)
+    if (nq * R < 2 * G) return 0;
+    if ((a.N / G) % 8 == 0 && (long)HW * (a.N / G) <= 256 * 80) return 0;      // the one-launch small GroupNorm kernel takes this one (norm.hip): faster than apply-only
+
+    int lim = max_chunks < GN_NCHUNK ? max_chunks : GN_NCHUNK;
+    // rows per chunk: a multiple of R dividing HW, as small as keeps nchunk <= lim (more workgroups), at least R
+    int RB = 0;
+    for (int cand = R; cand <= HW; cand += R) if (HW % cand == 0 && HW / cand <= lim) { RB = cand; break; }
+    if (!RB) return 0;
+    *R_out = R;
+    return HW / RB;
+}
+
 // tile selection: {BM, BN}
 struct TileSel { int bm, bn; };
 static const double pp_r224 = getenv("LDX_PP224_RATE") ? atof(getenv("LDX_PP224_RATE")) : 1.33, pp_r192 = getenv("LDX_PP192_RATE") ? atof(getenv("LDX_PP192_RATE")) : 1.29;   // 0: never
@@ -537,7 +622,12 @@ template <typename T>
 static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     const int S = (a.splitk > 1 && a.ws && !a.geglu) ? a.splitk : 1;
     if (a.mode == 0) launch_gemm_mode<T, 0>(a, S, s); else launch_gemm_mode<T, 1>(a, S, s);
-    if (S > 1) {
+    if (S > 1 && a.gn_partial) {       // reduce + GroupNorm statistics (gemm_gn_fuse set the geometry)
+        int R = 1;
+        const int nchunk = splitk_gn_geom(a, a.gn_hw, a.gn_G, a.gn_nchunk, &R);
+        if (nchunk != a.gn_nchunk) { fprintf(stderr, "ldx: split-K GroupNorm geometry mismatch (%d vs %d)\n", nchunk, a.gn_nchunk); abort(); }
+        hipLaunchKernelGGL((splitk_reduce_gn_kernel<T>), dim3(nchunk, a.M / a.gn_hw), dim3((a.N / 4) * R), (size_t)R * a.N * 2 * sizeof(float), s, a, R);
+    } else if (S > 1) {
         long total = (long)a.M * ((a.N + 3) / 4);
         int grid = (int)((total + 255) / 256); if (grid > 2048) grid = 2048;
         hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3(grid), dim3(256), 0, s, a);
@@ -549,7 +639,14 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
 int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
     static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
     if (off || a.f8 || a.C8 || a.geglu || a.ln_c1 || !a.C || G <= 0 || a.N % G || a.N % 4 || HW <= 0 || a.M % HW) return 0;
-    if (a.splitk > 1 && a.ws) return 0;
+    if (a.splitk > 1 && a.ws) {        // split-K: the reduce launch produces the statistics (splitk_reduce_gn_kernel)
+        static const bool sk_off = getenv("LDX_GN_FUSE_SPLITK") && atoi(getenv("LDX_GN_FUSE_SPLITK")) == 0;
+        int R = 1;
+        const int nchunk = sk_off ? 0 : splitk_gn_geom(a, HW, G, max_chunks, &R);
+        if (!nchunk) return 0;
+        a.gn_cpg = a.N / G; a.gn_G = G; a.gn_hw = HW; a.gn_nchunk = nchunk;
+        return nchunk;
+    }
     const int cpg = a.N / G;
     const TileSel t = gemm_tile(a.M, a.N, a.K, false, 1, true, a.mode == 0);
     int bm, bn;

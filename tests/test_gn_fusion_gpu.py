@@ -1,0 +1,46 @@
+"""GroupNorm statistics taken from the producer (conv / GEMM epilogue, round 3; split-K reduce launch, round 3 late) against the plain
+statistics pass: the switches are read once per process, so each variant runs the SD1.5 UNet at 1024^2 in a subprocess on the same seeded
+inputs.  The variants differ only in the fp32 summation order of the statistics (values summed are the stored 16-bit outputs in every
+variant), so the outputs agree to well inside the engine-vs-oracle tolerance (2.5e-2), and every fusion removes launches."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, %r)
+import ldx_amd as ldx
+cfg = ldx.UNetConfig.sd15()
+sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234)
+eng = ldx.UNetEngine(cfg, sd, device=0, dtype="bf16")
+g = torch.Generator().manual_seed(11)
+x = (torch.randn(2, 4, 128, 128, generator=g) * 3.0).cuda(); sig = torch.tensor([2.5, 2.5]).cuda(); ctx = torch.randn(2, 77, 768, generator=g).cuda()
+out = eng.denoise(x, sig, ctx).clone()
+assert torch.equal(out, eng.denoise(x, sig, ctx))
+torch.save({"out": out.cpu(), "launches": eng.plan_info()["launches"]}, sys.argv[1])
+"""
+
+
+def _run(env, path):
+    r = subprocess.run([sys.executable, "-c", SCRIPT % ROOT, path], cwd=ROOT, env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return torch.load(path)
+
+
+def test_gn_statistics_from_producers_match_the_plain_pass(ldx_lib):
+    with tempfile.TemporaryDirectory() as d:
+        plain = _run({"LDX_GN_FUSE": "0"}, os.path.join(d, "a.pt"))
+        epi = _run({"LDX_GN_FUSE_SPLITK": "0"}, os.path.join(d, "b.pt"))
+        full = _run({}, os.path.join(d, "c.pt"))
+    rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
+    r1, r2 = rel(epi["out"], plain["out"]), rel(full["out"], plain["out"])
+    print(f"launches plain {plain['launches']}  epilogue {epi['launches']}  + split-K reduce {full['launches']};  rel-L2 vs plain {r1:.2e} / {r2:.2e}")
+    assert plain["launches"] > epi["launches"] > full["launches"]
+    assert torch.isfinite(full["out"]).all() and r1 <= 1e-2 and r2 <= 1e-2      # measured 5.8e-3: one bf16 flip early in the net decorrelates the roundings after it
