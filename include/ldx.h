@@ -310,6 +310,13 @@ int ldx_op_layernorm(const void* X, int ldx, void* Y, int ldy, int rows, int C, 
                      const float* gamma, const float* beta, int dtype, void* stream);
 int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                      int B, int H, int Nq, int Mk, int D, float scale, int causal, int dtype, void* stream);
+/* Cross-attention sub-block of a BasicTransformerBlock as ONE kernel (reference: transformer.py:186-245 attn2 + Attention.py:100-124):
+ * H[m][:] += to_out(softmax(to_q(LayerNorm(H[m][:])) . K_b^T * scale) . V_b) + bo, in place, m in [0, M), image b = m / N.  Wq / Wo [C][C]
+ * 16-bit (row = output feature), K / V = the projected context (rows b * Mk + key, head h at columns h * (C / heads)).  Shapes the kernel
+ * takes: C = 320, heads = 8, Mk <= 80, N % 128 == 0, M % N == 0 — anything else returns LDX_EINVAL (use the separate ops). */
+int ldx_op_xattn_block(void* H, int ldh, int64_t M, int N, int C, int heads, const float* ln_gamma, const float* ln_beta, float eps,
+                       const void* Wq, const void* Wo, const float* bo, const void* K, int ldk, const void* V, int ldv, int Mk,
+                       float scale, int dtype, void* stream);
 /* attention with an additive fp32 score bias [H][>= Nq][bias_ld] (bias_ld >= Mk rounded up to 64), added before the scale */
 int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                           int B, int H, int Nq, int Mk, int D, float scale, const float* bias, int bias_ld,

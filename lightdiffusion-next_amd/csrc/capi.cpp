@@ -433,6 +433,17 @@ int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void*
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention");
 }
+int ldx_op_xattn_block(void* H, int ldh, int64_t M, int N, int C, int heads, const float* ln_gamma, const float* ln_beta, float eps,
+                       const void* Wq, const void* Wo, const float* bo, const void* K, int ldk, const void* V, int ldv, int Mk,
+                       float scale, int dtype, void* stream) {
+    XAttnArgs a{};
+    a.H = H; a.ldh = ldh; a.M = (long)M; a.N = N; a.C = C; a.heads = heads; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.eps = eps;
+    a.Wq = Wq; a.Wo = Wo; a.bo = bo; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.Mk = Mk; a.scale = scale;
+    if (!H || !ln_gamma || !ln_beta || !Wq || !Wo || !K || !V || M <= 0 || N <= 0 || ldh < C || !xattn_block_ok(a)) {
+        set_error("ldx_op_xattn_block: shape not taken by the fused kernel (C = 320, 8 heads, Mk <= 80, N % 128 == 0, M % N == 0)"); return LDX_EINVAL; }
+    launch_xattn_block(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_xattn_block");
+}
 int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
                           float scale, const float* bias, int bias_ld, int64_t bias_head_stride, int dtype, void* stream) {
     if (!Q || !K || !V || !O || !bias || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0 || bias_ld % 4 ||

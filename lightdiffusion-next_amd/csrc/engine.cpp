@@ -678,15 +678,30 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
         release(qkv);
         op_gemm("xf.o1", a, b.o1, h, h);                       // x += attn1(norm1(x))   (in place)
-        Act q = new_act(M, C);
-        ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
-        op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
-        if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
-        release(q);
-        op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
-        release(a);
+        XAttnArgs xa{};
+        xa.H = ptr(h); xa.ldh = h.ld; xa.M = M; xa.N = H * W; xa.C = C; xa.heads = heads; xa.ln_g = b.ln2.g; xa.ln_b = b.ln2.b; xa.eps = 1e-5f;
+        xa.Wq = b.q2.w; xa.Wo = b.o2.w; xa.bo = b.o2.b; xa.K = kvb; xa.ldk = kv_total; xa.V = kvb + (size_t)C * 2; xa.ldv = kv_total; xa.Mk = Mc;
+        xa.scale = q_prescale() ? 1.0f / 1.44269504088896340736f : 1.0f / std::sqrt((float)D);
+        if (!fold && !b.q2.b && xattn_block_ok(xa)) {
+            // LayerNorm + q projection + attention over the context + out projection + residual as ONE launch (xattn_block.hip)
+            Op o{}; o.kind = OP_XATTN; o.name = "xf.xattn2"; o.xa = xa;
+            o.flops = 2.0 * 2.0 * M * (double)C * C + 4.0 * B * heads * (double)(H * W) * Mc * D;
+            o.bytes = 2.0 * 2.0 * (double)M * C;
+            snprintf(o.klabel, sizeof(o.klabel), "xattn_block<%s>", dt == DT_BF16 ? "bf16" : "f16");
+            ops.push_back(o);
+            flops += o.flops;
+            release(a);
+        } else {
+            Act q = new_act(M, C);
+            ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
+            op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
+            if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
+            release(q);
+            op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
+            release(a);
+        }
         Act f = new_act(M, 4 * C);
         ln_gemm("xf.ln3", "xf.ff1", b.ln3, b.ff1, b.c1_ff1, f, true);        // GEGLU
         op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
@@ -926,6 +941,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             } break;
             case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
             case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
+            case OP_XATTN: launch_xattn_block(o.xa, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
             case OP_ATTN:

@@ -119,6 +119,19 @@ struct AttnArgs {
     void* O8; int ldo8; uint32_t* SO; int so_ld;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+
+// Cross-attention sub-block as one kernel (xattn_block.hip): H[m][:] += to_out(softmax(to_q(LayerNorm(H[m][:])) . K_b^T) . V_b) + bo, in place,
+// for m in [0, M), image b = m / N.  Wq / Wo: [C][C] 16-bit, row = output feature.  K / V: the projected context, rows b * Mk + key, head h at
+// columns h * D.  xattn_block_ok() says whether the kernel takes the shape (C = 320, 8 heads, Mk <= 80, N % 128 == 0; LDX_XATTN_FUSE=0: never).
+struct XAttnArgs {
+    void* H; int ldh; long M; int N, C, heads;
+    const float* ln_g; const float* ln_b; float eps;
+    const void* Wq; const void* Wo; const float* bo;
+    const void* K; int ldk; const void* V; int ldv; int Mk;
+    float scale;
+};
+bool xattn_block_ok(const XAttnArgs& a);
+void launch_xattn_block(const XAttnArgs& a, DType dt, hipStream_t s);
 bool attention_mx_out_ok(const AttnArgs& a);      // true if launch_attention will take a kernel that implements O8 / SO
 
 // ---------------------------------------------------------------------------------------------
