@@ -40,6 +40,12 @@ __device__ __forceinline__ float x_quad_sum(float v) {
 }
 }  // namespace
 
+#ifdef XA_ABLATE
+__device__ int xa_dbg = 0;       // timing ablations (wrong results): 1 no phase 1, 2 no phase 2, 4 no phase 3 MFMAs, 8 no epilogue, 16 no LN loads
+#define XA_DBG(bit) (xa_dbg & (bit))
+#else
+#define XA_DBG(bit) false
+#endif
 constexpr int XA_C = 320, XA_H = 8, XA_D = 40, XA_BM = 128, XA_MK = 80;
 constexpr int XA_AROW = XA_C * 2 + 16;            // 656 B: 16 consecutive rows start in 16 different 16-byte bank groups
 constexpr int XA_VROW = 96;                       // bytes per key row of a wave's V_h region (48 d; == 32 mod 64, see AttnCfg)
@@ -112,7 +118,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
         const int row = tid >> 2, part = tid & 3;
         const long m = m0 + row;
         float x[80];
-        if (m < p.M) {
+        if (m < p.M && !XA_DBG(16)) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
                 const uint4 u = *(const uint4*)(Hp + m * p.ldh + (part + 4 * j) * 8);
@@ -149,7 +155,8 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
 
     // ---- phase 1: Q^T of head `wave` ----
     f32x4 qT[3][8];
-    xa_project<T>((const T*)p.Wq, wave * XA_D, sA, l15, g4, qT);
+    if (!XA_DBG(1)) xa_project<T>((const T*)p.Wq, wave * XA_D, sA, l15, g4, qT);
+    else for (int t = 0; t < 3; ++t) for (int qt = 0; qt < 8; ++qt) qT[t][qt] = (f32x4){1.f, 1.f, 1.f, 1.f};
 
     // K fragments of the head, gathered in the k-slot order of the accumulator-as-B-operand trick:
     //   k-step 0: slots e < 4 -> d = 4 g4 + e (d-tile 0), e >= 4 -> d = 16 + 4 g4 + e - 4 (d-tile 1);  k-step 1: e < 4 -> d = 32 + 4 g4 + e (< 40), rest 0
@@ -188,6 +195,7 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
     const float c = p.scale * 1.44269504088896340736f;
 #pragma unroll
     for (int qt = 0; qt < 8; ++qt) {
+        if (XA_DBG(2)) break;
         V8 qb0, qb1;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -244,7 +252,20 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
 
     // ---- phase 3: out projection + bias + residual, in place ----
     f32x4 y[3][8];
-    xa_project<T>((const T*)p.Wo, wave * XA_D, sA, l15, g4, y);
+    if (!XA_DBG(4)) xa_project<T>((const T*)p.Wo, wave * XA_D, sA, l15, g4, y);
+    else for (int t = 0; t < 3; ++t) for (int qt = 0; qt < 8; ++qt) y[t][qt] = (f32x4){1.f, 1.f, 1.f, 1.f};
+    if (XA_DBG(8)) return;
+    // all 24 residual pieces of the lane in ONE round trip (as load -> add -> store per tile the round trips were serialised: the compiler cannot
+    // move a load of h above a store to h).  Fetching them before the projection instead costs 48 registers there: 192 B of scratch, 45 -> 60 us.
+    uint2 rr[3][8];
+#pragma unroll
+    for (int t = 0; t < 3; ++t)
+#pragma unroll
+        for (int qt = 0; qt < 8; ++qt) {
+            const long m = m0 + 16 * qt + l15;
+            const int nl = 16 * t + 4 * g4;
+            rr[t][qt] = (m < p.M && nl < XA_D && !XA_DBG(8)) ? *(const uint2*)(Hp + m * p.ldh + wave * XA_D + nl) : make_uint2(0u, 0u);
+        }
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nl = 16 * t + 4 * g4;
@@ -255,10 +276,9 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
         for (int qt = 0; qt < 8; ++qt) {
             const long m = m0 + 16 * qt + l15;
             if (m >= p.M) continue;
-            T* hp = Hp + m * p.ldh + n;
             float r4[4];
-            unpack4<T>(*(const uint2*)hp, r4);
-            *(uint2*)hp = pack4<T>(y[t][qt][0] + bo.x + r4[0], y[t][qt][1] + bo.y + r4[1], y[t][qt][2] + bo.z + r4[2], y[t][qt][3] + bo.w + r4[3]);
+            unpack4<T>(rr[t][qt], r4);
+            *(uint2*)(Hp + m * p.ldh + n) = pack4<T>(y[t][qt][0] + bo.x + r4[0], y[t][qt][1] + bo.y + r4[1], y[t][qt][2] + bo.z + r4[2], y[t][qt][3] + bo.w + r4[3]);
         }
     }
 }
@@ -272,6 +292,10 @@ template <typename T>
 static void launch_xattn_t(const XAttnArgs& a, hipStream_t s) {
     static DevOnce once;
     set_dyn_lds(once, (const void*)xattn_block_kernel<T>, XA_LDS);
+#ifdef XA_ABLATE
+    static const int dbg_once = []() { const int v = getenv("LDX_XA_DBG") ? atoi(getenv("LDX_XA_DBG")) : 0; (void)hipMemcpyToSymbol(HIP_SYMBOL(xa_dbg), &v, sizeof(int)); return v; }();
+    (void)dbg_once;
+#endif
     hipLaunchKernelGGL((xattn_block_kernel<T>), dim3((unsigned)((a.M + XA_BM - 1) / XA_BM)), dim3(512), XA_LDS, s, a);
 }
 void launch_xattn_block(const XAttnArgs& a, DType dt, hipStream_t s) {
