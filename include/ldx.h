@@ -317,6 +317,12 @@ int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void*
 int ldx_op_xattn_block(void* H, int ldh, int64_t M, int N, int C, int heads, const float* ln_gamma, const float* ln_beta, float eps,
                        const void* Wq, const void* Wo, const float* bo, const void* K, int ldk, const void* V, int ldv, int Mk,
                        float scale, int dtype, void* stream);
+/* Feed-forward sub-block of a BasicTransformerBlock as ONE kernel (reference: transformer.py:19-70, 240-244; Activation.py:6-31):
+ * H[m][:] += W2 . (a * gelu_erf(g)) + b2 with [a | g] = W1 . LayerNorm(H[m][:]) + b1, in place.  W1 [2 * inner][C] and b1 in the engine's GEGLU
+ * row layout: slab s (64 rows) = value rows of inner features 32 s .. 32 s + 31, then their gate rows (reference rows i and inner + i);
+ * W2 [C][inner].  Shapes the kernel takes: C = 320, inner = 1280 — anything else returns LDX_EINVAL (use the separate ops). */
+int ldx_op_ff_block(void* H, int ldh, int64_t M, int C, int inner, const float* ln_gamma, const float* ln_beta, float eps,
+                    const void* W1, const float* b1, const void* W2, const float* b2, int dtype, void* stream);
 /* attention with an additive fp32 score bias [H][>= Nq][bias_ld] (bias_ld >= Mk rounded up to 64), added before the scale */
 int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo,
                           int B, int H, int Nq, int Mk, int D, float scale, const float* bias, int bias_ld,

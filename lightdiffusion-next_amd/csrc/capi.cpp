@@ -444,6 +444,15 @@ int ldx_op_xattn_block(void* H, int ldh, int64_t M, int N, int C, int heads, con
     launch_xattn_block(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_xattn_block");
 }
+int ldx_op_ff_block(void* H, int ldh, int64_t M, int C, int inner, const float* ln_gamma, const float* ln_beta, float eps,
+                    const void* W1, const float* b1, const void* W2, const float* b2, int dtype, void* stream) {
+    FFBlockArgs a{};
+    a.H = H; a.ldh = ldh; a.M = (long)M; a.C = C; a.inner = inner; a.ln_g = ln_gamma; a.ln_b = ln_beta; a.eps = eps; a.W1 = W1; a.b1 = b1; a.W2 = W2; a.b2 = b2;
+    if (!H || !ln_gamma || !ln_beta || !W1 || !b1 || !W2 || M <= 0 || ldh < C || !ff_block_ok(a)) {
+        set_error("ldx_op_ff_block: shape not taken by the fused kernel (C = 320, inner = 1280)"); return LDX_EINVAL; }
+    launch_ff_block(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_ff_block");
+}
 int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
                           float scale, const float* bias, int bias_ld, int64_t bias_head_stride, int dtype, void* stream) {
     if (!Q || !K || !V || !O || !bias || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0 || bias_ld % 4 ||

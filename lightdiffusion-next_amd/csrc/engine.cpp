@@ -702,10 +702,23 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
             op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
             release(a);
         }
-        Act f = new_act(M, 4 * C);
-        ln_gemm("xf.ln3", "xf.ff1", b.ln3, b.ff1, b.c1_ff1, f, true);        // GEGLU
-        op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
-        release(f);
+        FFBlockArgs fa{};
+        fa.H = ptr(h); fa.ldh = h.ld; fa.M = M; fa.C = C; fa.inner = 4 * C; fa.ln_g = b.ln3.g; fa.ln_b = b.ln3.b; fa.eps = 1e-5f;
+        fa.W1 = b.ff1.w; fa.b1 = b.ff1.b; fa.W2 = b.ff2.w; fa.b2 = b.ff2.b;
+        if (!fold && ff_block_ok(fa)) {
+            // LayerNorm + GEGLU projection + down projection + residual as ONE launch (ff_block.hip): the [M][4C] activation never leaves the CUs
+            Op o{}; o.kind = OP_FFBLOCK; o.name = "xf.ffblock"; o.fb = fa;
+            o.flops = 2.0 * M * (double)C * (8.0 * C) + 2.0 * M * (double)C * (4.0 * C);
+            o.bytes = 2.0 * 2.0 * (double)M * C;
+            snprintf(o.klabel, sizeof(o.klabel), "ff_block<%s>", dt == DT_BF16 ? "bf16" : "f16");
+            ops.push_back(o);
+            flops += o.flops;
+        } else {
+            Act f = new_act(M, 4 * C);
+            ln_gemm("xf.ln3", "xf.ff1", b.ln3, b.ff1, b.c1_ff1, f, true);        // GEGLU
+            op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
+            release(f);
+        }
     }
     if (n.valid) release(n);
     op_gemm("xf.proj_out", h, x.proj_out, OUT, X);             // + x_in
@@ -942,6 +955,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
             case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
             case OP_XATTN: launch_xattn_block(o.xa, dt, ls); break;
+            case OP_FFBLOCK: launch_ff_block(o.fb, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
             case OP_ATTN:

@@ -42,11 +42,11 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
-              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN };
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
-    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa;
+    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb;
     void* cvt_out; size_t cvt_n;
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;

@@ -130,6 +130,15 @@ struct XAttnArgs {
     const void* K; int ldk; const void* V; int ldv; int Mk;
     float scale;
 };
+// Feed-forward sub-block as one kernel (ff_block.hip): H[m][:] += W2 . GEGLU(W1 . LayerNorm(H[m][:]) + b1) + b2, in place.  W1 [2 * inner][C] in
+// the engine's GEGLU row layout (slabs of 32 value rows + their 32 gate rows), erf GELU; W2 [C][inner].  ff_block_ok(): C = 320, inner = 1280.
+struct FFBlockArgs {
+    void* H; int ldh; long M; int C, inner;
+    const float* ln_g; const float* ln_b; float eps;
+    const void* W1; const float* b1; const void* W2; const float* b2;
+};
+bool ff_block_ok(const FFBlockArgs& a);
+void launch_ff_block(const FFBlockArgs& a, DType dt, hipStream_t s);
 bool xattn_block_ok(const XAttnArgs& a);
 void launch_xattn_block(const XAttnArgs& a, DType dt, hipStream_t s);
 bool attention_mx_out_ok(const AttnArgs& a);      // true if launch_attention will take a kernel that implements O8 / SO
