@@ -453,6 +453,15 @@ int ldx_op_ff_block(void* H, int ldh, int64_t M, int C, int inner, const float* 
     launch_ff_block(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_ff_block");
 }
+int ldx_op_rowgemm(const void* X, int ldx_, void* Y, int ldy, int64_t M, int N, int K, const void* W, const float* bias, const void* R, int ldr,
+                   int pro, const float* gamma, const float* beta, float eps, const float* partial, int nchunk, int HW, int dtype, void* stream) {
+    RowGemmArgs a{};
+    a.X = X; a.ldx = ldx_; a.Y = Y; a.ldy = ldy; a.M = (long)M; a.N = N; a.K = K; a.W = W; a.bias = bias; a.R = R; a.ldr = ldr;
+    a.pro = pro; a.g = gamma; a.b = beta; a.eps = eps; a.partial = partial; a.nchunk = nchunk; a.HW = HW; a.G = 32;
+    if (!X || !Y || !W || ldx_ < K || ldy < N || !rowgemm_ok(a)) { set_error("ldx_op_rowgemm: shape not taken (K = 320, N = 320 k, pro 0..2, GroupNorm: HW % 128 == 0, nchunk <= 256)"); return LDX_EINVAL; }
+    launch_rowgemm(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_rowgemm");
+}
 int ldx_op_attention_bias(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
                           float scale, const float* bias, int bias_ld, int64_t bias_head_stride, int dtype, void* stream) {
     if (!Q || !K || !V || !O || !bias || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0 || bias_ld % 4 ||

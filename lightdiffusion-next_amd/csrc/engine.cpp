@@ -581,6 +581,41 @@ void Engine::fuse_gn_stats() {
         snprintf(ops[i].klabel, sizeof(ops[i].klabel), "gn_apply(fused stats)");
     }
 }
+// Row-block GEMM (rowgemm.hip) in place of [LayerNorm +] an N = 320 k, K = 320 projection; false (nothing emitted) when the kernel does not take it
+bool Engine::op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw) {
+    RowGemmArgs a{};
+    a.X = ptr(X); a.ldx = X.ld; a.Y = ptr(Y); a.ldy = Y.ld; a.M = X.rows; a.N = w.N; a.K = w.K; a.W = w.w; a.bias = w.b;
+    a.R = R.valid ? ptr(R) : nullptr; a.ldr = R.ld; a.pro = pro; a.eps = 1e-5f;
+    if (nw) { a.g = nw->g; a.b = nw->b; }
+    if (!w.w || !rowgemm_ok(a)) return false;
+    Op o{}; o.kind = OP_ROWGEMM; o.name = name; o.rg = a;
+    o.flops = 2.0 * a.M * (double)a.N * a.K;
+    o.bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (R.valid ? 2 : 1));
+    snprintf(o.klabel, sizeof(o.klabel), "rowgemm<%s,%d>", dt == DT_BF16 ? "bf16" : "f16", pro);
+    ops.push_back(o);
+    flops += o.flops;
+    return true;
+}
+// GroupNorm (no SiLU, C = 320, statistics already written by its producer) directly followed by the N = K = 320 GEMM that reads its output
+// (SpatialTransformer norm + proj_in): the pair becomes one rowgemm launch with the GroupNorm apply as its prologue.  Runs after fuse_gn_stats().
+void Engine::fuse_gn_rowgemm() {
+    for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        if (ops[i].kind != OP_GN || ops[i + 1].kind != OP_GEMM) continue;
+        const GroupNormArgs& n = ops[i].gn;
+        const GemmArgs& g = ops[i + 1].g;
+        if (n.silu || n.stats_chunks <= 0 || n.stats_chunks > GN_NCHUNK || n.G != 32 || g.A != n.Y || g.lda != n.ldy || g.mode != 0 || g.K != n.C || g.geglu || g.ln_c1 ||
+            g.f8 || g.C8 || g.Cf || g.rowvec || g.splitk > 1 || g.gate || g.R2 || g.act || g.oscale != 0.f || g.gn_partial || (long)g.M != (long)n.B * n.HW || !g.C) continue;
+        RowGemmArgs a{};
+        a.X = n.X; a.ldx = n.ldx; a.Y = g.C; a.ldy = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.W = g.W; a.bias = g.bias; a.R = g.R; a.ldr = g.ldr;
+        a.pro = 2; a.g = n.gamma; a.b = n.beta; a.eps = n.eps; a.partial = n.partial; a.nchunk = n.stats_chunks; a.HW = n.HW; a.G = n.G;
+        if (!rowgemm_ok(a)) continue;
+        Op o{}; o.kind = OP_ROWGEMM; o.name = ops[i + 1].name; o.rg = a;
+        o.flops = ops[i + 1].flops; o.bytes = ops[i + 1].bytes;
+        snprintf(o.klabel, sizeof(o.klabel), "rowgemm<%s,2>", dt == DT_BF16 ? "bf16" : "f16");
+        ops[i] = o;
+        ops.erase(ops.begin() + (long)i + 1);
+    }
+}
 void Engine::op_ln(const char* name, Act X, Act Y, const NormW& n) {
     Op o{}; o.kind = OP_LN; o.name = name;
     LayerNormArgs& l = o.ln;
@@ -671,13 +706,15 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     for (int d = 0; d < x.depth; ++d) {
         const XfBlockW& b = x.blocks[d];
         Act qkv = new_act(M, 3 * C);
-        ln_gemm("xf.ln1", "xf.qkv", b.ln1, b.qkv, b.c1_qkv, qkv, false);
+        if (fold || b.qkv.b || !op_rowgemm("xf.ln1+qkv", h, b.qkv, qkv, Act{}, 1, &b.ln1))        // LayerNorm + q|k|v projection as one launch (C = 320)
+            ln_gemm("xf.ln1", "xf.qkv", b.ln1, b.qkv, b.c1_qkv, qkv, false);
         Act a = new_act(M, C);
         const char* base = (const char*)ptr(qkv);
         op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
         if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
         release(qkv);
-        op_gemm("xf.o1", a, b.o1, h, h);                       // x += attn1(norm1(x))   (in place)
+        if (!op_rowgemm("xf.o1", a, b.o1, h, h, 0, nullptr))
+            op_gemm("xf.o1", a, b.o1, h, h);                   // x += attn1(norm1(x))   (in place)
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
         XAttnArgs xa{};
@@ -865,6 +902,7 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         { Op o{}; o.kind = OP_FINISH; o.name = "finish"; ops.push_back(o); }
         release(ctx16); release(kvall);
         fuse_gn_stats();
+        fuse_gn_rowgemm();
         if (!bind) { arena_peak_dry = arena_peak; arena = saved_arena; }
     }
     pB2 = B2; ph = h; pw = w; pM = Mc;
@@ -956,6 +994,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
             case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
             case OP_XATTN: launch_xattn_block(o.xa, dt, ls); break;
             case OP_FFBLOCK: launch_ff_block(o.fb, dt, ls); break;
+            case OP_ROWGEMM: launch_rowgemm(o.rg, dt, ls); break;
             case OP_GN: launch_groupnorm(o.gn, dt, ls); break;
             case OP_LN: launch_layernorm(o.ln, dt, ls); break;
             case OP_ATTN:

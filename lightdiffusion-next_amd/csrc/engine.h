@@ -42,11 +42,11 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
-              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK };
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK, OP_ROWGEMM };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
-    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb;
+    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb; RowGemmArgs rg;
     void* cvt_out; size_t cvt_n;
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;
@@ -156,7 +156,9 @@ private:
     // GroupNorm workspace: gn_ws_rows producer rows per image + GN_FOLD folded rows, x 32 groups x 2 floats (ldx_kernels.h gn_workspace_rows)
     int gn_ws_rows = 256;
     size_t gn_ws_bytes(int B, long HWmax) { gn_ws_rows = (int)gn_workspace_rows(HWmax); return (size_t)B * (gn_ws_rows + GN_FOLD) * 32 * 2 * 4; }
-    void fuse_gn_stats();          // post-pass over ops: GroupNorms whose input was just written by a fusable GEMM / conv get their statistics from its epilogue
+    void fuse_gn_stats();
+    void fuse_gn_rowgemm();                               // GroupNorm (producer statistics) + proj_in -> one rowgemm launch
+    bool op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw);          // post-pass over ops: GroupNorms whose input was just written by a fusable GEMM / conv get their statistics from its epilogue
     // per-call bindings read by exec_ops
     const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false; int b_xB = 0, g_xB = 0;
     const int* b_ids = nullptr; float* b_out2 = nullptr;

@@ -139,6 +139,17 @@ struct FFBlockArgs {
 };
 bool ff_block_ok(const FFBlockArgs& a);
 void launch_ff_block(const FFBlockArgs& a, DType dt, hipStream_t s);
+// Row-block GEMM with a normalisation prologue (rowgemm.hip): Y[m][0:N) = pro(X[m][0:K)) . W^T + bias (+ R), K = 320, N a multiple of 320.
+// pro 0: identity, 1: LayerNorm(g, b, eps), 2: GroupNorm apply (32 groups; statistics = the producer-written partial sums of the consumer
+// GroupNorm's layout, `nchunk` rows per image of HW pixels).  Y may be X's own buffer only for pro = 0 with R = Y (rows are workgroup-private).
+struct RowGemmArgs {
+    const void* X; int ldx; void* Y; int ldy; long M; int N, K;
+    const void* W; const float* bias; const void* R; int ldr;
+    int pro; const float* g; const float* b; float eps;
+    const float* partial; int nchunk, HW, G;
+};
+bool rowgemm_ok(const RowGemmArgs& a);
+void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s);
 bool xattn_block_ok(const XAttnArgs& a);
 void launch_xattn_block(const XAttnArgs& a, DType dt, hipStream_t s);
 bool attention_mx_out_ok(const AttnArgs& a);      // true if launch_attention will take a kernel that implements O8 / SO

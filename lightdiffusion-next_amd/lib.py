@@ -112,6 +112,7 @@ _SIGS = {
     "ldx_op_attention": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _i, _i, _vp]),
     "ldx_op_xattn_block": (_i, [_vp, _i, _i64, _i, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp, _i, _i, _f, _i, _vp]),
     "ldx_op_ff_block": (_i, [_vp, _i, _i64, _i, _i, _vp, _vp, _f, _vp, _vp, _vp, _vp, _i, _vp]),
+    "ldx_op_rowgemm": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _vp, _vp, _vp, _i, _i, _vp, _vp, _f, _vp, _i, _i, _i, _vp]),
     "ldx_op_attention_bias": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _i64, _i, _vp]),
     "ldx_op_skinny": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp]),
 }
