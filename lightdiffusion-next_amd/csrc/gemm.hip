@@ -429,7 +429,7 @@ __global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const GemmArgs p,
     const size_t stride = (size_t)p.M * p.N;
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     if (rl < R) {
-        constexpr int U = 4;                    // rows in flight per thread (the partial loads of U rows are issued together)
+        constexpr int U = 8;                    // rows in flight per thread (the partial loads of U rows are issued together)
         for (int r = rl; r < RB; r += R * U) {
             float v[U][4];
             bool live[U];
