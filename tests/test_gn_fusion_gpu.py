@@ -44,3 +44,15 @@ def test_gn_statistics_from_producers_match_the_plain_pass(ldx_lib):
     print(f"launches plain {plain['launches']}  epilogue {epi['launches']}  + split-K reduce {full['launches']};  rel-L2 vs plain {r1:.2e} / {r2:.2e}")
     assert plain["launches"] > epi["launches"] > full["launches"]
     assert torch.isfinite(full["out"]).all() and r1 <= 1e-2 and r2 <= 1e-2      # measured 5.8e-3: one bf16 flip early in the net decorrelates the roundings after it
+
+
+def test_fused_c320_sub_blocks_match_the_separate_launches(ldx_lib):
+    """rowgemm / xattn_block / ff_block (LayerNorm + q|k|v, GroupNorm + proj_in, to_out + residual, the cross-attention and feed-forward sub-blocks
+    of the C = 320 level as single launches) against the same engine with the separate launches: same roundings, other summation orders."""
+    with tempfile.TemporaryDirectory() as d:
+        sep = _run({"LDX_XATTN_FUSE": "0", "LDX_FF_FUSE": "0", "LDX_ROWGEMM": "0"}, os.path.join(d, "a.pt"))
+        fused = _run({}, os.path.join(d, "b.pt"))
+    r = float((fused["out"].double() - sep["out"].double()).norm() / sep["out"].double().norm())
+    print(f"launches separate {sep['launches']}  fused {fused['launches']};  rel-L2 {r:.2e}")
+    assert sep["launches"] - fused["launches"] >= 30          # 35 at 1024^2: 6 per transformer block + the proj_in pair, 5 blocks
+    assert torch.isfinite(fused["out"]).all() and r <= 1e-2
