@@ -417,7 +417,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
 // rounded outputs are per column; LDS [R][N][2]; then one thread per (group, statistic) adds its gn_cpg columns over the R row lanes in a
 // fixed order (deterministic, no atomics).  Same partial layout as the GEMM epilogue's: gn_partial[b][chunk][G][2].
 template <typename T>
-__global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const GemmArgs p, const int R) {
+__global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p, const int R) {
     extern __shared__ float red_gn[];
     const int nq = p.N >> 2, tid = threadIdx.x;
     const int rl = tid / nq, n = (tid - rl * nq) * 4;
@@ -479,12 +479,12 @@ __global__ __launch_bounds__(512) void splitk_reduce_gn_kernel(const GemmArgs p,
         p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + g) * 2 + st] = a;
     }
 }
-// geometry of that launch: R row lanes of N / 4 threads (<= 512 threads, >= 2 * G), chunks of RB rows; 0 = not applicable
+// geometry of that launch: R row lanes of N / 4 threads (<= 1024 threads, >= 2 * G), chunks of RB rows; 0 = not applicable
 static int splitk_gn_geom(const GemmArgs& a, int HW, int G, int max_chunks, int* R_out) {
     if (a.N % 4 || !a.C || a.N % G || HW <= 0 || a.M % HW) return 0;
     const int nq = a.N / 4;
     if (nq > 512 || nq < 1) return 0;
-    int R = nq <= 128 ? 4 : (nq <= 256 ? 2 : 1);        // a power of two (chunks of R rows must tile the image)
+    int R = nq <= 128 ? 8 : (nq <= 256 ? 4 : 2);        // a power of two (chunks of R rows must tile the image); up to 1024 threads: the kernel is latency-bound
     if (nq * R < 2 * G) return 0;
     if ((a.N / G) % 8 == 0 && (long)HW * (a.N / G) <= 256 * 80) return 0;      // the one-launch small GroupNorm kernel takes this one (norm.hip): faster than apply-only
 
