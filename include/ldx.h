@@ -323,10 +323,11 @@ int ldx_op_xattn_block(void* H, int ldh, int64_t M, int N, int C, int heads, con
  * W2 [C][inner].  Shapes the kernel takes: C = 320, inner = 1280 — anything else returns LDX_EINVAL (use the separate ops). */
 int ldx_op_ff_block(void* H, int ldh, int64_t M, int C, int inner, const float* ln_gamma, const float* ln_beta, float eps,
                     const void* W1, const float* b1, const void* W2, const float* b2, int dtype, void* stream);
-/* Row-block GEMM with a normalisation prologue (csrc/rowgemm.hip): Y[m][0:N) = pro(X[m][0:320)) . W^T + bias (+ R[m][:]), N = 320 or 960, W [N][320].
+/* Row-block GEMM with a normalisation prologue (csrc/rowgemm.hip): Y[m][0:N) = pro(X[m][0:K)) . W^T + bias (+ R[m][:]), K = 320 or 640, N a multiple of K, W [N][K].
  * pro 0: identity; 1: LayerNorm(gamma, beta, eps) (transformer.py:199 norm1 in front of to_q|k|v); 2: GroupNorm apply, 32 groups
  * (transformer.py:361-367 norm in front of proj_in) with the statistics given as partial sums partial[b][chunk][32][2] = (sum, sum of squares)
- * over any split of image b's HW pixels into `nchunk` <= 256 chunks (what the producing conv's epilogue writes).  Other shapes: LDX_EINVAL. */
+ * over any split of image b's HW pixels (HW a multiple of 128 at K = 320, of 64 at K = 640) into `nchunk` <= 256 chunks (what the producing
+ * conv's epilogue writes).  Other shapes: LDX_EINVAL. */
 int ldx_op_rowgemm(const void* X, int ldx, void* Y, int ldy, int64_t M, int N, int K, const void* W, const float* bias, const void* R, int ldr,
                    int pro, const float* gamma, const float* beta, float eps, const float* partial, int nchunk, int HW, int dtype, void* stream);
 /* attention with an additive fp32 score bias [H][>= Nq][bias_ld] (bias_ld >= Mk rounded up to 64), added before the scale */

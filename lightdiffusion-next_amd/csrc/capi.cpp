@@ -458,7 +458,7 @@ int ldx_op_rowgemm(const void* X, int ldx_, void* Y, int ldy, int64_t M, int N, 
     RowGemmArgs a{};
     a.X = X; a.ldx = ldx_; a.Y = Y; a.ldy = ldy; a.M = (long)M; a.N = N; a.K = K; a.W = W; a.bias = bias; a.R = R; a.ldr = ldr;
     a.pro = pro; a.g = gamma; a.b = beta; a.eps = eps; a.partial = partial; a.nchunk = nchunk; a.HW = HW; a.G = 32;
-    if (!X || !Y || !W || ldx_ < K || ldy < N || !rowgemm_ok(a)) { set_error("ldx_op_rowgemm: shape not taken (K = 320, N = 320 k, pro 0..2, GroupNorm: HW % 128 == 0, nchunk <= 256)"); return LDX_EINVAL; }
+    if (!X || !Y || !W || ldx_ < K || ldy < N || !rowgemm_ok(a)) { set_error("ldx_op_rowgemm: shape not taken (K = 320 or 640, N a multiple of K, pro 0..2, GroupNorm: HW % (40960 / K) == 0, nchunk <= 256)"); return LDX_EINVAL; }
     launch_rowgemm(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_rowgemm");
 }

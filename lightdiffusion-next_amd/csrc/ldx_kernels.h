@@ -139,7 +139,7 @@ struct FFBlockArgs {
 };
 bool ff_block_ok(const FFBlockArgs& a);
 void launch_ff_block(const FFBlockArgs& a, DType dt, hipStream_t s);
-// Row-block GEMM with a normalisation prologue (rowgemm.hip): Y[m][0:N) = pro(X[m][0:K)) . W^T + bias (+ R), K = 320, N a multiple of 320.
+// Row-block GEMM with a normalisation prologue (rowgemm.hip): Y[m][0:N) = pro(X[m][0:K)) . W^T + bias (+ R), K = 320 or 640, N a multiple of K.
 // pro 0: identity, 1: LayerNorm(g, b, eps), 2: GroupNorm apply (32 groups; statistics = the producer-written partial sums of the consumer
 // GroupNorm's layout, `nchunk` rows per image of HW pixels).  Y may be X's own buffer only for pro = 0 with R = Y (rows are workgroup-private).
 struct RowGemmArgs {

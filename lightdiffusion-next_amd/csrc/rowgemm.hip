@@ -1,5 +1,5 @@
-// Row-block GEMM for the C = 320 level of the SD1.5 UNet:  Y[m][0:N) = pro(X[m][0:320)) . W^T + bias (+ R[m][:]),  N = 320 or 960, with the
-// prologue pro = identity | LayerNorm | GroupNorm-apply computed by the workgroup that owns the 128 rows.  Same scheme as xattn_block.hip /
+// Row-block GEMM for the C = 320 and C = 640 levels of the SD1.5 UNet:  Y[m][0:N) = pro(X[m][0:C)) . W^T + bias (+ R[m][:]),  N = C or 3 C, with the
+// prologue pro = identity | LayerNorm | GroupNorm-apply computed by the workgroup that owns the rows (128 at C = 320, 64 at C = 640).  Same scheme as xattn_block.hip /
 // ff_block.hip: pro(X) lives in LDS as the B operand of every MFMA, weight rows go from L2 straight into A-operand registers (wave w owns output
 // features 40 w .. 40 w + 39 of each 320-wide pass), so the N = K = 320 projections of a transformer block stop paying a LayerNorm / GroupNorm
 // launch and a normalised copy of the activation in front of them:
@@ -17,13 +17,20 @@
 
 namespace ldx {
 
-constexpr int RG_C = 320, RG_BM = 128;
-constexpr int RG_AROW = RG_C * 2 + 16;
-constexpr int RG_ABYTES = RG_BM * RG_AROW;
-constexpr int RG_LDS = RG_ABYTES + 2 * RG_C * 4 + 8 * 64 * 4 + 64 * 4;
+// Geometry per channel count CC (= K): the workgroup's rows always hold 128 * 320 elements, so that A fits LDS next to the small tables
+//   CC = 320: 128 rows, 4 lanes per row in the prologue, 8 query tiles, grid (M / 128, 1)
+//   CC = 640:  64 rows, 8 lanes per row,               4 query tiles, grid (M / 64, 2): the two workgroups of a row block own the two halves of
+//              the output features (each runs the prologue; every weight row is still fetched by one wave per row block)
+template <int CC> struct RgGeom {
+    static constexpr int BM = 128 * 320 / CC, QT = BM / 16, LPR = 512 / BM, NH = CC / 320;
+    static constexpr int AROW = CC * 2 + 16, ABYTES = BM * AROW;
+    static constexpr int LDS = ABYTES + 2 * CC * 4 + 8 * 64 * 4 + 64 * 4;
+};
 
-template <typename T, int PRO>
+template <typename T, int PRO, int CC>
 __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
+    using G = RgGeom<CC>;
+    constexpr int RG_C = CC, RG_BM = G::BM, RG_AROW = G::AROW, RG_ABYTES = G::ABYTES, QT = G::QT, LPR = G::LPR;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     using V8 = typename Vec<T>::v8;
     char* sA = smem;
@@ -38,10 +45,10 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     const T* __restrict__ Xp = (const T*)p.X;
     const T* __restrict__ W = (const T*)p.W;
 
-    // ---- prologue: 128 rows -> 16-bit A in LDS ----
+    // ---- prologue: BM rows -> 16-bit A in LDS ----
     if (PRO == 1) { for (int i = tid; i < RG_C; i += 512) { sSc[i] = p.g[i]; sSh[i] = p.b[i]; } }
     if (PRO == 2) {
-        const int b = (int)(m0 / p.HW);                                  // HW % 128 == 0: the rows of a workgroup belong to one image
+        const int b = (int)(m0 / p.HW);                                  // HW % BM == 0: the rows of a workgroup belong to one image
         const int g = tid & 31, st = (tid >> 5) & 1, sl = tid >> 6;       // 8 slices x 32 groups x {sum, sum of squares}
         float a = 0.f;
         {
@@ -75,14 +82,14 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
         }
     }
     {
-        const int row = tid >> 2, part = tid & 3;
+        const int row = tid / LPR, part = tid % LPR;
         const long m = m0 + row;
         uint4 raw[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) raw[j] = (m < p.M) ? *(const uint4*)(Xp + m * p.ldx + (part + 4 * j) * 8) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 10; ++j) raw[j] = (m < p.M) ? *(const uint4*)(Xp + m * p.ldx + (part + LPR * j) * 8) : make_uint4(0, 0, 0, 0);
         if (PRO == 0) {
 #pragma unroll
-            for (int j = 0; j < 10; ++j) *(uint4*)(sA + row * RG_AROW + (part + 4 * j) * 16) = raw[j];
+            for (int j = 0; j < 10; ++j) *(uint4*)(sA + row * RG_AROW + (part + LPR * j) * 16) = raw[j];
         } else {
             float x[80];
 #pragma unroll
@@ -97,18 +104,18 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
                 float su = 0.f;
 #pragma unroll
                 for (int e = 0; e < 80; ++e) su += x[e];
-                su += dpp_f<0xB1>(su); su += dpp_f<0x4E>(su);
+                su += dpp_f<0xB1>(su); su += dpp_f<0x4E>(su); if (LPR == 8) su += dpp_f<0x141>(su);
                 mean = su * (1.0f / RG_C);
                 float sq = 0.f;
 #pragma unroll
                 for (int e = 0; e < 80; ++e) { const float d = x[e] - mean; sq = fmaf(d, d, sq); }
-                sq += dpp_f<0xB1>(sq); sq += dpp_f<0x4E>(sq);
+                sq += dpp_f<0xB1>(sq); sq += dpp_f<0x4E>(sq); if (LPR == 8) sq += dpp_f<0x141>(sq);
                 rstd = rsqrtf(sq * (1.0f / RG_C) + p.eps);
             }
             __syncthreads();                             // gamma / beta (LayerNorm) or scale / shift (GroupNorm) in LDS
 #pragma unroll
             for (int j = 0; j < 10; ++j) {
-                const int c0 = (part + 4 * j) * 8;
+                const int c0 = (part + LPR * j) * 8;
                 float f[8];
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
@@ -120,16 +127,17 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     __syncthreads();
 
     // ---- N / 320 passes: Y^T[320 pass + 40 wave ..][q] = W rows . A^T, + bias (+ residual) ----
-    const int npass = p.N / RG_C;
+    const int nown = p.N / G::NH;                       // output features of this workgroup: [blockIdx.y * nown, + nown), in passes of 320 (40 per wave)
+    const int npass = nown / 320;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
-        const int wrow0 = pass * RG_C + wave * 40;
+        const int wrow0 = (int)blockIdx.y * nown + pass * 320 + wave * 40;
         constexpr int NKS = RG_C / 32, PD = 3;
-        f32x4 acc[3][8];
+        f32x4 acc[3][QT];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int qt = 0; qt < 8; ++qt) acc[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int qt = 0; qt < QT; ++qt) acc[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
         uint4 wf[PD + 1][3];
         auto wload = [&](int ks, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -143,22 +151,22 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks + PD < NKS) wload(ks + PD, (ks + PD) % (PD + 1));
-            V8 af[8];
+            V8 af[QT];
 #pragma unroll
-            for (int qt = 0; qt < 8; ++qt) af[qt] = as_v8<T>(*(const uint4*)(sA + (16 * qt + l15) * RG_AROW + (ks * 32 + g4 * 8) * 2));
+            for (int qt = 0; qt < QT; ++qt) af[qt] = as_v8<T>(*(const uint4*)(sA + (16 * qt + l15) * RG_AROW + (ks * 32 + g4 * 8) * 2));
 #pragma unroll
             for (int t = 0; t < 3; ++t) {
                 const V8 w8 = as_v8<T>(wf[ks % (PD + 1)][t]);
 #pragma unroll
-                for (int qt = 0; qt < 8; ++qt) acc[t][qt] = mfma16(w8, af[qt], acc[t][qt]);
+                for (int qt = 0; qt < QT; ++qt) acc[t][qt] = mfma16(w8, af[qt], acc[t][qt]);
             }
             __builtin_amdgcn_sched_barrier(0);            // without it hipcc hoists the fragment reads of later k-steps (1 KiB of scratch)
         }
-        uint2 rr[3][8];
+        uint2 rr[3][QT];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
-            for (int qt = 0; qt < 8; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const long m = m0 + 16 * qt + l15;
                 const int nl = 16 * t + 4 * g4;
                 rr[t][qt] = (p.R && m < p.M && nl < 40) ? *(const uint2*)((const T*)p.R + m * p.ldr + wrow0 + nl) : make_uint2(0u, 0u);
@@ -170,7 +178,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
             const int n = wrow0 + nl;
             const float4 bo = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int qt = 0; qt < 8; ++qt) {
+            for (int qt = 0; qt < QT; ++qt) {
                 const long m = m0 + 16 * qt + l15;
                 if (m >= p.M) continue;
                 float r4[4];
@@ -183,17 +191,27 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
 
 bool rowgemm_ok(const RowGemmArgs& a) {
     static const bool off = getenv("LDX_ROWGEMM") && atoi(getenv("LDX_ROWGEMM")) == 0;
-    if (off || a.K != RG_C || a.N <= 0 || a.N % RG_C || a.M <= 0 || a.ldx % 8 || a.ldy % 4 || (a.R && a.ldr % 4) || a.pro < 0 || a.pro > 2) return false;
+    static const bool off640 = getenv("LDX_ROWGEMM640") && atoi(getenv("LDX_ROWGEMM640")) == 0;
+    if (off || (a.K != 320 && a.K != 640) || (a.K == 640 && off640) || a.N <= 0 || a.N % a.K || a.M <= 0 || a.ldx % 8 || a.ldy % 4 || (a.R && a.ldr % 4) || a.pro < 0 || a.pro > 2) return false;
+    const int bm = 128 * 320 / a.K;
     if (a.pro >= 1 && (!a.g || !a.b)) return false;
-    if (a.pro == 2 && (!a.partial || a.G != 32 || a.HW % RG_BM || a.M % a.HW || a.nchunk < 1 || a.nchunk > GN_NCHUNK)) return false;
+    if (a.pro == 2 && (!a.partial || a.G != 32 || a.HW % bm || a.M % a.HW || a.nchunk < 1 || a.nchunk > GN_NCHUNK)) return false;
     return true;
+}
+template <typename T, int PRO, int CC>
+static void launch_rowgemm_inst(const RowGemmArgs& a, hipStream_t s) {
+    using G = RgGeom<CC>;
+    static DevOnce once;
+    set_dyn_lds(once, (const void*)rowgemm_kernel<T, PRO, CC>, G::LDS);
+    hipLaunchKernelGGL((rowgemm_kernel<T, PRO, CC>), dim3((unsigned)((a.M + G::BM - 1) / G::BM), G::NH), dim3(512), G::LDS, s, a);
 }
 template <typename T>
 static void launch_rowgemm_t(const RowGemmArgs& a, hipStream_t s) {
-    const dim3 grid((unsigned)((a.M + RG_BM - 1) / RG_BM));
-    if (a.pro == 0) { static DevOnce once; set_dyn_lds(once, (const void*)rowgemm_kernel<T, 0>, RG_LDS); hipLaunchKernelGGL((rowgemm_kernel<T, 0>), grid, dim3(512), RG_LDS, s, a); }
-    else if (a.pro == 1) { static DevOnce once; set_dyn_lds(once, (const void*)rowgemm_kernel<T, 1>, RG_LDS); hipLaunchKernelGGL((rowgemm_kernel<T, 1>), grid, dim3(512), RG_LDS, s, a); }
-    else { static DevOnce once; set_dyn_lds(once, (const void*)rowgemm_kernel<T, 2>, RG_LDS); hipLaunchKernelGGL((rowgemm_kernel<T, 2>), grid, dim3(512), RG_LDS, s, a); }
+    if (a.K == 320) {
+        if (a.pro == 0) launch_rowgemm_inst<T, 0, 320>(a, s); else if (a.pro == 1) launch_rowgemm_inst<T, 1, 320>(a, s); else launch_rowgemm_inst<T, 2, 320>(a, s);
+    } else {
+        if (a.pro == 0) launch_rowgemm_inst<T, 0, 640>(a, s); else if (a.pro == 1) launch_rowgemm_inst<T, 1, 640>(a, s); else launch_rowgemm_inst<T, 2, 640>(a, s);
+    }
 }
 void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s) {
     if (dt == DT_BF16) launch_rowgemm_t<__bf16>(a, s); else launch_rowgemm_t<_Float16>(a, s);

@@ -21,11 +21,13 @@ def _rel(a, b):
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("pro,N,res", [(0, 320, True), (0, 320, False), (1, 960, False), (1, 320, True), (2, 320, False)])
 @pytest.mark.parametrize("B,HW", [(2, 1024), (1, 384)])
-def test_rowgemm_vs_torch_and_separate_ops(ldx, ldx_lib, dt, pro, N, res, B, HW):
+@pytest.mark.parametrize("K", [320, 640])
+def test_rowgemm_vs_torch_and_separate_ops(ldx, ldx_lib, dt, pro, N, res, B, HW, K):
     L = ldx_lib
     td, code = DT[dt]
-    K, M = 320, B * HW
-    g = torch.Generator(device="cuda").manual_seed(pro * 100 + N + B + HW)
+    M = B * HW
+    N = N * K // 320                                     # 320 / 960 at K = 320, 640 / 1920 at K = 640
+    g = torch.Generator(device="cuda").manual_seed(pro * 100 + N + B + HW + K)
     rn = lambda *s: torch.randn(*s, device="cuda", generator=g)
     X = (rn(M, K) * 1.5 + 0.4).to(td)
     W = (rn(N, K) / math.sqrt(K)).to(td); bias = 0.1 * rn(N)
@@ -64,7 +66,7 @@ def test_rowgemm_vs_torch_and_separate_ops(ldx, ldx_lib, dt, pro, N, res, B, HW)
     ldx.lib.check(L.ldx_op_rowgemm(_p(X), K, _p(Y), N, M, N, K, _p(W), _p(bias), _p(R), N, pro, _p(gamma), _p(beta), eps, _p(partial), nchunk, HW, code, _st()), "rowgemm")
     torch.cuda.synchronize()
     r_f, r_s = _rel(Y.float(), ref), _rel(sep.float(), ref)
-    print(f"{dt} pro{pro} N{N} res{int(res)} B{B} HW{HW}: fused vs torch {r_f:.2e} (separate ops {r_s:.2e}), fused vs separate {_rel(Y.float(), sep.float()):.2e}")
+    print(f"{dt} K{K} pro{pro} N{N} res{int(res)} B{B} HW{HW}: fused vs torch {r_f:.2e} (separate ops {r_s:.2e}), fused vs separate {_rel(Y.float(), sep.float()):.2e}")
     tol = 5e-3 if dt == "bf16" else 7e-4
     assert torch.isfinite(Y).all() and r_f <= tol and r_f <= 1.5 * r_s + 1e-4
 
@@ -83,5 +85,6 @@ def test_rowgemm_in_place_residual(ldx, ldx_lib):
 
 
 def test_rowgemm_refuses_other_shapes(ldx, ldx_lib):
-    t = torch.zeros(128, 640, device="cuda", dtype=torch.bfloat16)
-    assert ldx_lib.ldx_op_rowgemm(_p(t), 640, _p(t), 640, 128, 640, 640, _p(t), None, None, 0, 0, None, None, 0.0, None, 0, 0, 0, _st()) != 0
+    t = torch.zeros(1280, 1280, device="cuda", dtype=torch.bfloat16)
+    assert ldx_lib.ldx_op_rowgemm(_p(t), 1280, _p(t), 1280, 128, 1280, 1280, _p(t), None, None, 0, 0, None, None, 0.0, None, 0, 0, 0, _st()) != 0      # K = 1280
+    assert ldx_lib.ldx_op_rowgemm(_p(t), 640, _p(t), 1280, 128, 960, 640, _p(t), None, None, 0, 0, None, None, 0.0, None, 0, 0, 0, _st()) != 0        # N % K
