@@ -131,6 +131,20 @@ if __name__ == "__main__":
         for (M, N, K) in ((2048, 1280, 1280), (8192, 640, 640), (32768, 320, 320), (512, 1280, 1280)):
             wn = max(1, int(400e6 / (N * K * 2))); an = max(1, int(400e6 / (M * K * 2)))
             gemm_cold(M, N, K, 1, 1); gemm_cold(M, N, K, 1, wn); gemm_cold(M, N, K, an, 1); gemm_cold(M, N, K, an, wn)
+    if what == "rowblock":   # the C = 320 row-block kernels (rowgemm LN + q|k|v, xattn_block, ff_block) at M = 32768, hipGraph-timed
+        M, Cc, inner, Mk = 32768, 320, 1280, 77
+        rn = lambda *s_: torch.randn(*s_, device="cuda")
+        h = rn(M, Cc).bfloat16(); gamma, beta = 1 + 0.1 * rn(Cc), 0.1 * rn(Cc)
+        Wq = (rn(Cc, Cc) / math.sqrt(Cc)).bfloat16(); Wo = (rn(Cc, Cc) / math.sqrt(Cc)).bfloat16(); bo = 0.1 * rn(Cc)
+        Wqkv = (rn(3 * Cc, Cc) / math.sqrt(Cc)).bfloat16(); qkv = torch.empty(M, 3 * Cc, device="cuda", dtype=torch.bfloat16)
+        kv = rn(2 * Mk, 2 * Cc).bfloat16()
+        W1 = (rn(2 * inner, Cc) / math.sqrt(Cc)).bfloat16(); b1 = 0.1 * rn(2 * inner); W2 = (rn(Cc, inner) / math.sqrt(inner)).bfloat16(); b2 = 0.1 * rn(Cc)
+        for name, fl, fn in (
+            ("rowgemm LN + q|k|v (N = 960)", 2.0 * M * 960 * Cc, lambda: L.ldx_op_rowgemm(p(h), Cc, p(qkv), 3 * Cc, M, 3 * Cc, Cc, p(Wqkv), None, None, 0, 1, p(gamma), p(beta), 1e-5, None, 0, 0, 0, st())),
+            ("xattn_block (77 keys)", 4.0 * M * Cc * Cc + 4.0 * M * Mk * Cc, lambda: L.ldx_op_xattn_block(p(h), Cc, M, M // 2, Cc, 8, p(gamma), p(beta), 1e-5, p(Wq), p(Wo), p(bo), p(kv), 2 * Cc, p(kv[:, Cc:]), 2 * Cc, Mk, 1 / math.sqrt(40), 0, st())),
+            ("ff_block (inner 1280)", 2.0 * M * Cc * 3 * inner, lambda: L.ldx_op_ff_block(p(h), Cc, M, Cc, inner, p(gamma), p(beta), 1e-5, p(W1), p(b1), p(W2), p(b2), 0, st()))):
+            ms = timeit_graph(fn, 20)
+            print(f"{name}: {ms * 1000:.1f} us  {fl / ms / 1e9:.1f} TFLOP/s")
     if what == "deep":     # weight-streaming convs / GEMMs of the deep UNet levels (M = 512 / 2048): run with LDX_GEMM_TILE / LDX_SPLITK sweeps
         def convg(B, H, Cin, Cout):
             X = torch.randn(B, H, H, Cin, device="cuda").bfloat16()
