@@ -14,6 +14,7 @@
 #include <stdlib.h>
 #include "ldx_device.h"
 #include "ldx_kernels.h"
+#include "rowblock_store.h"
 
 namespace ldx {
 
@@ -24,7 +25,8 @@ namespace ldx {
 template <int CC> struct RgGeom {
     static constexpr int BM = 128 * 320 / CC, QT = BM / 16, LPR = 512 / BM, NH = CC / 320;
     static constexpr int AROW = CC * 2 + 16, ABYTES = BM * AROW;
-    static constexpr int LDS = ABYTES + 2 * CC * 4 + 8 * 64 * 4 + 64 * 4;
+    static constexpr int TAB = 2 * CC * 4 + 8 * 64 * 4 + 64 * 4;          // scale / shift + fold scratch
+    static constexpr int LDS = ABYTES + TAB + RB_STAGE_BYTES;                // + the output stage's tile (rowblock_store.h)
 };
 
 template <typename T, int PRO, int CC>
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     float* sMR = sRed + 8 * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int l15 = lane & 15, g4 = lane >> 4;
+    const int l15_0 = lane & 15, g4_0 = lane >> 4;
     const long m0 = (long)blockIdx.x * RG_BM;
     const T* __restrict__ Xp = (const T*)p.X;
     const T* __restrict__ W = (const T*)p.W;
@@ -131,6 +133,8 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     const int npass = nown / 320;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
+        int l15 = l15_0, g4 = g4_0;                       // opaque per pass: otherwise LICM precomputes every per-lane address of the pass (weights,
+        asm volatile("" : "+v"(l15), "+v"(g4));           // residual, stores) ahead of the loop and they spill
         const int wrow0 = (int)blockIdx.y * nown + pass * 320 + wave * 40;
         constexpr int NKS = RG_C / 32, PD = 3;
         f32x4 acc[3][QT];
@@ -162,6 +166,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
             }
             __builtin_amdgcn_sched_barrier(0);            // without it hipcc hoists the fragment reads of later k-steps (1 KiB of scratch)
         }
+        __builtin_amdgcn_sched_barrier(0);                // the residual loads stay behind the MFMA loop (hoisted above it they cost 48 registers there: scratch)
         uint2 rr[3][QT];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
@@ -174,25 +179,23 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
             const int nl = 16 * t + 4 * g4;
-            if (nl >= 40) continue;
-            const int n = wrow0 + nl;
+            const int n = wrow0 + (nl < 40 ? nl : 0);
             const float4 bo = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) {
-                const long m = m0 + 16 * qt + l15;
-                if (m >= p.M) continue;
                 float r4[4];
                 unpack4<T>(rr[t][qt], r4);
-                *(uint2*)((T*)p.Y + m * p.ldy + n) = pack4<T>(acc[t][qt][0] + bo.x + r4[0], acc[t][qt][1] + bo.y + r4[1], acc[t][qt][2] + bo.z + r4[2], acc[t][qt][3] + bo.w + r4[3]);
+                rr[t][qt] = pack4<T>(acc[t][qt][0] + bo.x + r4[0], acc[t][qt][1] + bo.y + r4[1], acc[t][qt][2] + bo.z + r4[2], acc[t][qt][3] + bo.w + r4[3]);
             }
         }
+        rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB);
     }
 }
 
 bool rowgemm_ok(const RowGemmArgs& a) {
     static const bool off = getenv("LDX_ROWGEMM") && atoi(getenv("LDX_ROWGEMM")) == 0;
     static const bool off640 = getenv("LDX_ROWGEMM640") && atoi(getenv("LDX_ROWGEMM640")) == 0;
-    if (off || (a.K != 320 && a.K != 640) || (a.K == 640 && off640) || a.N <= 0 || a.N % a.K || a.M <= 0 || a.ldx % 8 || a.ldy % 4 || (a.R && a.ldr % 4) || a.pro < 0 || a.pro > 2) return false;
+    if (off || (a.K != 320 && a.K != 640) || (a.K == 640 && off640) || a.N <= 0 || a.N % a.K || a.M <= 0 || a.ldx % 8 || a.ldy % 8 || (a.R && a.ldr % 4) || a.pro < 0 || a.pro > 2) return false;
     const int bm = 128 * 320 / a.K;
     if (a.pro >= 1 && (!a.g || !a.b)) return false;
     if (a.pro == 2 && (!a.partial || a.G != 32 || a.HW % bm || a.M % a.HW || a.nchunk < 1 || a.nchunk > GN_NCHUNK)) return false;

@@ -17,6 +17,7 @@
 #include <stdlib.h>
 #include "ldx_device.h"
 #include "ldx_kernels.h"
+#include "rowblock_store.h"
 
 namespace ldx {
 
@@ -269,18 +270,17 @@ __global__ __launch_bounds__(512, 1) void xattn_block_kernel(const XAttnArgs p) 
 #pragma unroll
     for (int t = 0; t < 3; ++t) {
         const int nl = 16 * t + 4 * g4;
-        if (nl >= XA_D) continue;
-        const int n = wave * XA_D + nl;
+        const int n = wave * XA_D + (nl < XA_D ? nl : 0);
         const float4 bo = p.bo ? *(const float4*)(p.bo + n) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int qt = 0; qt < 8; ++qt) {
-            const long m = m0 + 16 * qt + l15;
-            if (m >= p.M) continue;
             float r4[4];
             unpack4<T>(rr[t][qt], r4);
-            *(uint2*)(Hp + m * p.ldh + n) = pack4<T>(y[t][qt][0] + bo.x + r4[0], y[t][qt][1] + bo.y + r4[1], y[t][qt][2] + bo.z + r4[2], y[t][qt][3] + bo.w + r4[3]);
+            rr[t][qt] = pack4<T>(y[t][qt][0] + bo.x + r4[0], y[t][qt][1] + bo.y + r4[1], y[t][qt][2] + bo.z + r4[2], y[t][qt][3] + bo.w + r4[3]);
         }
     }
+    // whole 640-byte rows through an LDS tile (rowblock_store.h); the V regions are free: their fragments went to registers before phase 2
+    rb_store_rows<T, 8>(Hp, p.ldh, m0, p.M, 0, wave, l15, g4, tid, rr, smem + XA_ABYTES);
 }
 
 bool xattn_block_ok(const XAttnArgs& a) {
