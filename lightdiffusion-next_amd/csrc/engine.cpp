@@ -732,11 +732,14 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
             release(a);
         } else {
             Act q = new_act(M, C);
-            ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
+            static const bool x2 = !(getenv("LDX_ROWGEMM_X2") && atoi(getenv("LDX_ROWGEMM_X2")) == 0);      // A/B switch for the two uses below
+            if (!x2 || fold || b.q2.b || !op_rowgemm("xf.ln2+q2", h, b.q2, q, Act{}, 1, &b.ln2))          // C = 640: LayerNorm + q projection as one row-block launch
+                ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
             op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
             if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
             release(q);
-            op_gemm("xf.o2", a, b.o2, h, h);                       // x += attn2(norm2(x), ctx)
+            if (!x2 || !op_rowgemm("xf.o2", a, b.o2, h, h, 0, nullptr))
+                op_gemm("xf.o2", a, b.o2, h, h);                   // x += attn2(norm2(x), ctx)
             release(a);
         }
         FFBlockArgs fa{};
