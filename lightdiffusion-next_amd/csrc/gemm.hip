@@ -488,7 +488,8 @@ static int splitk_gn_geom(const GemmArgs& a, int HW, int G, int max_chunks, int*
     if (nq * R < 2 * G) return 0;
     if ((a.N / G) % 8 == 0 && (long)HW * (a.N / G) <= 256 * 80) return 0;      // the one-launch small GroupNorm kernel takes this one (norm.hip): faster than apply-only
 
-    int lim = max_chunks < GN_NCHUNK ? max_chunks : GN_NCHUNK;
+    static const int lim_env = getenv("LDX_SKGN_CHUNKS") ? atoi(getenv("LDX_SKGN_CHUNKS")) : GN_NCHUNK;      // experiment switch: chunks per image (fewer = fatter workgroups)
+    int lim = max_chunks < lim_env ? max_chunks : lim_env;
     // rows per chunk: a multiple of R dividing HW, as small as keeps nchunk <= lim (more workgroups), at least R
     int RB = 0;
     for (int cand = R; cand <= HW; cand += R) if (HW % cand == 0 && HW / cand <= lim) { RB = cand; break; }
