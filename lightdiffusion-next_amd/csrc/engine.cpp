@@ -569,6 +569,19 @@ void Engine::op_gn(const char* name, Act X, Act Y, int B, int HW, const NormW& n
 // bit-for-bit equality between different BATCH SIZES (the producer's tile shape, hence the summation order, depends on M).
 void Engine::fuse_gn_stats() {
     for (size_t i = 1; i < ops.size(); ++i) {
+        if (ops[i].kind == OP_GN && ops[i - 1].kind == OP_ROWGEMM) {          // row-block producer (proj_out + residual): statistics from its output stage
+            RowGemmArgs& r = ops[i - 1].rg;
+            GroupNormArgs& n = ops[i].gn;
+            const int bm = 128 * 320 / r.K;
+            static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
+            if (off || r.pro == 2 || r.Y != n.X || r.ldy != n.ldx || r.N != n.C || r.N != r.K || n.G != 32 || (long)r.M != (long)n.B * n.HW || n.HW % bm || n.HW / bm > gn_ws_rows ||
+                (n.C / n.G) % 8 == 0 && (long)n.HW * (n.C / n.G) <= 256 * 80) continue;
+            r.gn_out = n.partial; r.gn_nchunk = n.HW / bm; r.HW = n.HW;
+            n.stats_chunks = n.HW / bm;
+            ops[i].bytes = 2.0 * 2.0 * (double)n.B * n.HW * n.C;
+            snprintf(ops[i].klabel, sizeof(ops[i].klabel), "gn_apply(fused stats)");
+            continue;
+        }
         if (ops[i].kind != OP_GN || ops[i - 1].kind != OP_GEMM) continue;
         GemmArgs& g = ops[i - 1].g;
         GroupNormArgs& n = ops[i].gn;
@@ -761,7 +774,9 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         }
     }
     if (n.valid) release(n);
-    op_gemm("xf.proj_out", h, x.proj_out, OUT, X);             // + x_in
+    static const bool po = !(getenv("LDX_ROWGEMM_PO") && atoi(getenv("LDX_ROWGEMM_PO")) == 0);      // A/B switch
+    if (!po || !op_rowgemm("xf.proj_out", h, x.proj_out, OUT, X, 0, nullptr))
+        op_gemm("xf.proj_out", h, x.proj_out, OUT, X);         // + x_in
     release(h);
 }
 

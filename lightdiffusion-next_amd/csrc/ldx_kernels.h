@@ -147,6 +147,9 @@ struct RowGemmArgs {
     const void* W; const float* bias; const void* R; int ldr;
     int pro; const float* g; const float* b; float eps;
     const float* partial; int nchunk, HW, G;
+    // gn_out != null (engine only, pro != 2, N == K): the consumer of Y is a GroupNorm over [M / HW][HW][N] — every workgroup also writes the sum / sum of
+    // squares of the 16-bit values it stores, per group, to gn_out[b][chunk = its row block within the image][32][2] (gn_nchunk = HW / rows per block)
+    float* gn_out; int gn_nchunk;
 };
 bool rowgemm_ok(const RowGemmArgs& a);
 void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s);

@@ -188,6 +188,38 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
                 rr[t][qt] = pack4<T>(acc[t][qt][0] + bo.x + r4[0], acc[t][qt][1] + bo.y + r4[1], acc[t][qt][2] + bo.z + r4[2], acc[t][qt][3] + bo.w + r4[3]);
             }
         }
+        if (p.gn_out) {       // statistics of the stored values for the consumer GroupNorm (the layout gn_apply_kernel folds), fixed order: deterministic
+            float cs[3][4], cq[3][4];
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[t][r] = 0.f; cq[t][r] = 0.f; }
+#pragma unroll
+                for (int qt = 0; qt < QT; ++qt) {
+                    float v4[4];
+                    unpack4<T>(rr[t][qt], v4);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { cs[t][r] += v4[r]; cq[t][r] = fmaf(v4[r], v4[r], cq[t][r]); }
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { cs[t][r] = row16_sum(cs[t][r]); cq[t][r] = row16_sum(cq[t][r]); }
+                const int nl = 16 * t + 4 * g4;
+                if (l15 == 0 && nl < 40) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) { sSc[(wave * 40 + nl + r) * 2] = cs[t][r]; sSc[(wave * 40 + nl + r) * 2 + 1] = cq[t][r]; }
+                }
+            }
+            __syncthreads();
+            const int cpg = p.N / 32;
+            if (tid < (320 / cpg) * 2) {
+                const int gl = tid >> 1, st = tid & 1;
+                float a = 0.f;
+                for (int c = 0; c < cpg; ++c) a += sSc[(gl * cpg + c) * 2 + st];
+                const int bimg = (int)(m0 / p.HW), chunk = (int)((m0 - (long)bimg * p.HW) / RG_BM);
+                const int g0 = ((int)blockIdx.y * nown + pass * 320) / cpg;
+                p.gn_out[(((long)bimg * p.gn_nchunk + chunk) * 32 + g0 + gl) * 2 + st] = a;
+            }
+        }
         rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB);
     }
 }
