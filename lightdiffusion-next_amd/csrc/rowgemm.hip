@@ -6,6 +6,7 @@
 //   LayerNorm + q|k|v projection   (transformer.py:199-204 norm1 + attn1.to_q/k/v; Attention.py:100-113)        pro = 1, N = 960
 //   GroupNorm + proj_in            (transformer.py:361-367 norm + proj_in, a 1x1 conv = a GEMM in NHWC)          pro = 2, N = 320
 //   attn1.to_out + residual        (transformer.py:205-209)                                                        pro = 0, N = 320, R = Y
+//   proj_out + x_in                (transformer.py:372-377), with the next GroupNorm's statistics from the output stage  pro = 0, N = C, gn_out
 // The GroupNorm prologue reads the per-(image, chunk, group) partial sums its producer wrote (GemmArgs::gn_partial / splitk_reduce_gn_kernel) and
 // folds them exactly as gn_apply_kernel does (8 slices in chunk order, then the slices in order; y = fma(x, rstd * gamma, beta - mean * rstd * gamma)),
 // so the normalised 16-bit values — and therefore the GEMM — are the ones the separate launches produce.
