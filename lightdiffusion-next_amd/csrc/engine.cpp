@@ -594,13 +594,20 @@ void Engine::fuse_gn_stats() {
         snprintf(ops[i].klabel, sizeof(ops[i].klabel), "gn_apply(fused stats)");
     }
 }
+// Planner rule for the row-block kernels (rowgemm / xattn_block / ff_block): one workgroup per row block and one workgroup per CU, so below ~3/4 of the
+// CUs the tile GEMMs win (SD1.5 512^2 has 64 row blocks per launch: step 6.14 -> 6.83 ms with the row-block kernels) and smaller problems stay on the
+// separate launches.  LDX_ROWBLOCK_MINWG moves the limit (0: always).
+static bool rowblock_fills_chip(long workgroups) {
+    static const long min_wg = getenv("LDX_ROWBLOCK_MINWG") ? atol(getenv("LDX_ROWBLOCK_MINWG")) : 192;
+    return workgroups >= min_wg;
+}
 // Row-block GEMM (rowgemm.hip) in place of [LayerNorm +] an N = 320 k, K = 320 projection; false (nothing emitted) when the kernel does not take it
 bool Engine::op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw) {
     RowGemmArgs a{};
     a.X = ptr(X); a.ldx = X.ld; a.Y = ptr(Y); a.ldy = Y.ld; a.M = X.rows; a.N = w.N; a.K = w.K; a.W = w.w; a.bias = w.b;
     a.R = R.valid ? ptr(R) : nullptr; a.ldr = R.ld; a.pro = pro; a.eps = 1e-5f;
     if (nw) { a.g = nw->g; a.b = nw->b; }
-    if (!w.w || !rowgemm_ok(a)) return false;
+    if (!w.w || !rowgemm_ok(a) || !rowblock_fills_chip((a.M + 128 * 320 / a.K - 1) / (128 * 320 / a.K) * (a.K / 320))) return false;
     Op o{}; o.kind = OP_ROWGEMM; o.name = name; o.rg = a;
     o.flops = 2.0 * a.M * (double)a.N * a.K;
     o.bytes = 2.0 * ((double)a.M * a.K + (double)a.N * a.K + (double)a.M * a.N * (R.valid ? 2 : 1));
@@ -621,7 +628,7 @@ void Engine::fuse_gn_rowgemm() {
         RowGemmArgs a{};
         a.X = n.X; a.ldx = n.ldx; a.Y = g.C; a.ldy = g.ldc; a.M = g.M; a.N = g.N; a.K = g.K; a.W = g.W; a.bias = g.bias; a.R = g.R; a.ldr = g.ldr;
         a.pro = 2; a.g = n.gamma; a.b = n.beta; a.eps = n.eps; a.partial = n.partial; a.nchunk = n.stats_chunks; a.HW = n.HW; a.G = n.G;
-        if (!rowgemm_ok(a)) continue;
+        if (!rowgemm_ok(a) || !rowblock_fills_chip((a.M + 128 * 320 / a.K - 1) / (128 * 320 / a.K) * (a.K / 320))) continue;
         Op o{}; o.kind = OP_ROWGEMM; o.name = ops[i + 1].name; o.rg = a;
         o.flops = ops[i + 1].flops; o.bytes = ops[i + 1].bytes;
         snprintf(o.klabel, sizeof(o.klabel), "rowgemm<%s,2>", dt == DT_BF16 ? "bf16" : "f16");
@@ -734,7 +741,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         xa.H = ptr(h); xa.ldh = h.ld; xa.M = M; xa.N = H * W; xa.C = C; xa.heads = heads; xa.ln_g = b.ln2.g; xa.ln_b = b.ln2.b; xa.eps = 1e-5f;
         xa.Wq = b.q2.w; xa.Wo = b.o2.w; xa.bo = b.o2.b; xa.K = kvb; xa.ldk = kv_total; xa.V = kvb + (size_t)C * 2; xa.ldv = kv_total; xa.Mk = Mc;
         xa.scale = q_prescale() ? 1.0f / 1.44269504088896340736f : 1.0f / std::sqrt((float)D);
-        if (!fold && !b.q2.b && xattn_block_ok(xa)) {
+        if (!fold && !b.q2.b && xattn_block_ok(xa) && rowblock_fills_chip((M + 127) / 128)) {
             // LayerNorm + q projection + attention over the context + out projection + residual as ONE launch (xattn_block.hip)
             Op o{}; o.kind = OP_XATTN; o.name = "xf.xattn2"; o.xa = xa;
             o.flops = 2.0 * 2.0 * M * (double)C * C + 4.0 * B * heads * (double)(H * W) * Mc * D;
@@ -758,7 +765,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         FFBlockArgs fa{};
         fa.H = ptr(h); fa.ldh = h.ld; fa.M = M; fa.C = C; fa.inner = 4 * C; fa.ln_g = b.ln3.g; fa.ln_b = b.ln3.b; fa.eps = 1e-5f;
         fa.W1 = b.ff1.w; fa.b1 = b.ff1.b; fa.W2 = b.ff2.w; fa.b2 = b.ff2.b;
-        if (!fold && ff_block_ok(fa)) {
+        if (!fold && ff_block_ok(fa) && rowblock_fills_chip((M + 127) / 128)) {
             // LayerNorm + GEGLU projection + down projection + residual as ONE launch (ff_block.hip): the [M][4C] activation never leaves the CUs
             Op o{}; o.kind = OP_FFBLOCK; o.name = "xf.ffblock"; o.fb = fa;
             o.flops = 2.0 * M * (double)C * (8.0 * C) + 2.0 * M * (double)C * (4.0 * C);
