@@ -1008,6 +1008,19 @@ static void launch_attn_d(const AttnArgs& a, hipStream_t s) {
 
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {
     if (a.Nq <= 0 || a.B <= 0) return;
+    // D = 40 self-attention of the large levels: the software-pipelined one-wave-per-SIMD kernel (attn_pipe.hip) when its 256-query workgroups
+    // fill the chip.  LDX_ATTN_PIPE=0 restores attn32ap / attn32; LDX_ATTN_PIPE_THR=<x> overrides the rescale threshold (tests).  Read per call:
+    // one process A/Bs both kernels.
+    if (attn_pipe_ok(a)) {
+        const char* e = getenv("LDX_ATTN_PIPE");
+        const char* m = getenv("LDX_ATTN_PIPE_MINWG");
+        const long wgs = (long)(a.Nq / 256) * a.H * a.B;
+        if ((!e || atoi(e) != 0) && wgs >= (m ? atol(m) : 256)) {
+            const char* t = getenv("LDX_ATTN_PIPE_THR");
+            launch_attn_pipe(a, dt, s, t ? (float)atof(t) : __builtin_nanf(""));
+            return;
+        }
+    }
     if (dt == DT_BF16) launch_attn_d<__bf16>(a, s); else launch_attn_d<_Float16>(a, s);
 }
 

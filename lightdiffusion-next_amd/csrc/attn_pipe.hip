@@ -1,0 +1,432 @@
+// Software-pipelined flash attention for D = 40 (SD1.5 level 0 self-attention: the step's largest kernel) — round 4.
+// Reference call site: Attention.py:100-124 through AttentionMethods.py:107-150 (F.scaled_dot_product_attention, no mask).
+//
+// Same transposed 32x32x16 formulation, operand layouts and LDS strides as attn32_kernel (attention.hip):
+//   S^T[key][q] = K . Q^T (contraction padded 40 -> 48), O^T[d][q] += V^T . P^T, lane l owns query l & 31 of a 32-query tile,
+//   softmax denominator from the ones column of V at d = 40.
+// What is different is the schedule, built on three measurements (profiles/ubench/README.md round 3, MI355X guide "Two waves per SIMD"):
+// the matrix phase of one wave and the softmax phase of its SIMD partner do not overlap, a wave's OWN VALU work does issue in the
+// shadow of its own MFMAs (about five single-issue fillers per 32-cycle 32x32x16 gap), and the kernel was bound by instructions per key.
+//   * ONE wave per SIMD (256 threads, all 512 registers): 64 queries per wave, 256 per workgroup.
+//   * Software pipeline over 64-key blocks: in slot t the matrix pipe runs QK^T(t+1) (12 MFMAs) and PV(t-1) (16 MFMAs) while the
+//     VALU turns S'(t) into P(t) and takes the maximum of S'(t+1); S' and P are double-buffered in registers (loop unrolled by two).
+//   * Lazy INTEGER reference maximum carried inside the QK^T contraction: the contraction is padded 40 -> 48 anyway, so K's LDS rows hold
+//     the constant 1 at d = 40 and 41 and the Q fragment holds -m_ref of the lane's query there as a 16-bit hi / lo pair (exact for
+//     |m_ref| < 6e4): the MFMA result already is S' = s - m_ref, and the softmax is exp2 / pack / max only — no per-element subtract or
+//     scale (scale * log2(e) is folded into the Q fragments once; the engine passes scale = 1 / log2(e) with the softmax scale folded into
+//     the q weights, for which this is the identity).  m_ref starts as ceil(max of block 0).  The maximum of S'(t+1) is taken late in
+//     slot t, BEFORE any of its exponentials: only if it exceeds THR the reference is raised by an integer dl (rare path at the end of the
+//     slot, all in place: O *= 2^-dl, P(t) by exponent subtraction — exact, P(t) <= 2^THR is finite by the previous check —
+//     S'(t+1) -= dl, Q slots rewritten).  So P <= 2^THR always, which 16-bit P and fp32 accumulation hold without loss (the
+//     denominator comes from the same rounded P through the ones column of V).
+//   * Register classes are explicit: a 512-register wave has 256 arch VGPRs (all the VALU can address) and 256 AGPRs.  hipcc puts every
+//     MFMA result into AGPRs at this budget and copies S' back and forth (1358 v_accvgpr moves per two slots in the first build), so the
+//     QK^T MFMAs are inline asm with constraints: S' (MFMA -> VALU) in arch VGPRs, Q / K fragments in AGPRs (LDS reads and staging loads land
+//     there directly).  The PV MFMAs stay builtins: O is only touched by the matrix pipe, so hipcc's AGPR home is the right one, and their
+//     V^T / P operands may sit in either class.  The asm is opaque to the hazard recogniser: S' is only read by the VALU five or more
+//     MFMA gaps after its last MFMA, or behind explicit s_nop runs (prologue).
+//   * Issue order is pinned gap by gap (one MFMA, its fillers, sched_barrier(0)); the softmax pieces are asm blocks of fixed internal
+//     order (a VALU read of a transcendental result needs a wait state: the pack of piece k - 1 sits in front of the exponentials of piece k).
+//   * K / V tiles register-staged a slot ahead (buffer loads at the top of the slot, LDS stores in its second half), 2-deep rings, one
+//     s_barrier per slot between the two matrix phases; fragment reads for the next slot are issued behind the MFMAs that last use the registers.
+// Shapes taken: D = 40, Nq % 256 == 0, Mk % 128 == 0, Mk >= 256, no mask / bias; everything else stays on attn32* (attention.hip).
+#include <stdlib.h>
+#include <math.h>
+#include <type_traits>
+#include <utility>
+#include "ldx_device.h"
+#include "ldx_kernels.h"
+
+namespace ldx {
+
+typedef __attribute__((ext_vector_type(4))) short ap_s16x4;
+typedef __attribute__((ext_vector_type(4))) int ap_i32x4;
+typedef __attribute__((ext_vector_type(2))) int ap_i32x2;
+__device__ __forceinline__ ap_i32x2 ap_lds_read_tr16(const char* p) {
+    return __builtin_bit_cast(ap_i32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) ap_s16x4*)p));
+}
+template <typename V> __device__ __forceinline__ ap_i32x4 ap_bits(const V& v) { return __builtin_bit_cast(ap_i32x4, v); }
+template <typename T> struct ApT;
+template <> struct ApT<__bf16>   { static constexpr int split = 256, expsh = 7, maxdl = 255; static constexpr float thr = 32.0f; };
+template <> struct ApT<_Float16> { static constexpr int split = 2048, expsh = 10, maxdl = 31; static constexpr float thr = 15.0f; };
+
+// ---- 32x32x16 MFMAs with explicit register classes.  S' chains: first (C = 0), middle, last (its Q operand is the pinned reference-carrying
+// fragment of q tile QT: a[64:67] / a[68:71]); O^T chains: tile (qt, dt) pinned to a[32 qt + 16 dt .. +15].
+#define AP_BF16 "v_mfma_f32_32x32x16_bf16"
+#define AP_F16 "v_mfma_f32_32x32x16_f16"
+template <typename T> __device__ __forceinline__ void ap_sacc0(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile(AP_BF16 " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
+    else asm volatile(AP_F16 " %0, %1, %2, 0" : "=&v"(d) : "a"(a), "a"(b));
+}
+template <typename T> __device__ __forceinline__ void ap_sacc(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile(AP_BF16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    else asm volatile(AP_F16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+}
+template <typename T, int QT> __device__ __forceinline__ void ap_sacc_ref(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) {
+        asm volatile(AP_BF16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    } else {
+        asm volatile(AP_F16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
+    }
+}
+#define AP_OACC(OPC, CONS) asm volatile(OPC " %0, %1, %2, %0" : CONS(d) : "a"(a), "v"(b))
+template <typename T, int QD> __device__ __forceinline__ void ap_oacc(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) {
+        AP_OACC(AP_BF16, "+a");
+    } else {
+        AP_OACC(AP_F16, "+a");
+    }
+}
+// ---- rare path pieces on the pinned registers
+#define AP_RS1(r) "v_accvgpr_read_b32 %1, a" #r "\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 a" #r ", %1\n\t"
+#define AP_RS16(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15) \
+    AP_RS1(a0) AP_RS1(a1) AP_RS1(a2) AP_RS1(a3) AP_RS1(a4) AP_RS1(a5) AP_RS1(a6) AP_RS1(a7) AP_RS1(a8) AP_RS1(a9) AP_RS1(a10) AP_RS1(a11) AP_RS1(a12) AP_RS1(a13) AP_RS1(a14) AP_RS1(a15)
+template <int QT> __device__ __forceinline__ void ap_rescale(f32x16& o0, f32x16& o1, float al) {       // both d tiles of q tile QT *= al
+    float t;
+    if constexpr (QT == 0) {
+        asm volatile(AP_RS16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) "s_nop 1" : "+{a[0:15]}"(o0), "=&v"(t) : "v"(al));
+        asm volatile(AP_RS16(16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31) "s_nop 1" : "+{a[16:31]}"(o1), "=&v"(t) : "v"(al));
+    } else {
+        asm volatile(AP_RS16(32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47) "s_nop 1" : "+{a[32:47]}"(o0), "=&v"(t) : "v"(al));
+        asm volatile(AP_RS16(48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63) "s_nop 1" : "+{a[48:63]}"(o1), "=&v"(t) : "v"(al));
+    }
+}
+// dword 0 of the pinned Q fragment of q tile QT := refbits on the lanes of mask (the h2 = 1 half: elements 0, 1 = d 40, 41)
+template <int QT> __device__ __forceinline__ void ap_setref(ap_i32x4& q2, unsigned refbits, unsigned long long mask) {
+    unsigned t;
+    if constexpr (QT == 0) asm volatile("v_accvgpr_read_b32 %1, a64\n\tv_cndmask_b32_e64 %1, %1, %2, %3\n\tv_accvgpr_write_b32 a64, %1\n\ts_nop 3" : "+{a[64:67]}"(q2), "=&v"(t) : "v"(refbits), "s"(mask));
+    else asm volatile("v_accvgpr_read_b32 %1, a68\n\tv_cndmask_b32_e64 %1, %1, %2, %3\n\tv_accvgpr_write_b32 a68, %1\n\ts_nop 3" : "+{a[68:71]}"(q2), "=&v"(t) : "v"(refbits), "s"(mask));
+}
+// ---- softmax pieces.  Piece k: exp2 of element a, the pack of piece k - 2's results (px, py -> one dword of P), exp2 of element b.  A VALU read of a
+// fresh transcendental result needs a wait state; hipcc cannot see the order inside an asm block and pads every block whose inputs were written by
+// the block right in front of it with s_nop 0, so the pack trails by TWO pieces and the pieces rotate through three temporary pairs.  As separate C++ statements the exponentials drifted out of the gap they were written in.
+template <typename T> __device__ __forceinline__ int ap_piece(float a, float b, float& x, float& y, float px, float py) {
+    int r;
+    if constexpr (std::is_same<T, __bf16>::value) asm("v_exp_f32 %1, %3\n\tv_cvt_pk_bf16_f32 %0, %5, %6\n\tv_exp_f32 %2, %4" : "=&v"(r), "=&v"(x), "=&v"(y) : "v"(a), "v"(b), "v"(px), "v"(py));
+    else asm("v_exp_f32 %1, %3\n\tv_cvt_pk_f16_f32 %0, %5, %6\n\tv_exp_f32 %2, %4" : "=&v"(r), "=&v"(x), "=&v"(y) : "v"(a), "v"(b), "v"(px), "v"(py));
+    return r;
+}
+__device__ __forceinline__ void ap_piece0(float a, float b, float& x, float& y) {
+    asm("v_exp_f32 %0, %2\n\tv_exp_f32 %1, %3" : "=&v"(x), "=&v"(y) : "v"(a), "v"(b));
+}
+template <typename T> __device__ __forceinline__ int ap_pack(float x, float y) {
+    int r;
+    if constexpr (std::is_same<T, __bf16>::value) asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    else asm("v_cvt_pk_f16_f32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(y));
+    return r;
+}
+// maximum of eight accumulator registers (asm: fmaxf on asm outputs would first canonicalise every input)
+__device__ __forceinline__ float ap_max8(float x0, float x1, float x2, float x3, float x4, float x5, float x6, float x7) {
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3\n\tv_max3_f32 %0, %0, %4, %5\n\tv_max3_f32 %0, %0, %6, %7\n\tv_max_f32 %0, %0, %8" : "=&v"(m) : "v"(x0), "v"(x1), "v"(x2), "v"(x3), "v"(x4), "v"(x5), "v"(x6), "v"(x7));
+    return m;
+}
+__device__ __forceinline__ float ap_max4(float a, float b, float c, float d) {
+    float m; asm("v_max3_f32 %0, %1, %2, %3\n\tv_max_f32 %0, %0, %4" : "=&v"(m) : "v"(a), "v"(b), "v"(c), "v"(d)); return m;
+}
+__device__ __forceinline__ float ap_max2(float a, float b) { float r; asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+template <int... I, typename F> __device__ __forceinline__ void ap_for(std::integer_sequence<int, I...>, F&& f) { (f(std::integral_constant<int, I>{}), ...); }
+template <int LO, int... I> constexpr auto ap_range_impl(std::integer_sequence<int, I...>) { return std::integer_sequence<int, (LO + I)...>{}; }
+template <int LO, int HI> constexpr auto ap_range() { return ap_range_impl<LO>(std::make_integer_sequence<int, HI - LO>{}); }
+template <int N> using ap_ic = std::integral_constant<int, N>;
+
+template <typename T>
+__global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const float thr) {
+    constexpr int KROWB = 144, VROWB = 192, KVB = 64, D = 40, DCH = 5;
+    constexpr int KBYTES = KVB * KROWB, VBYTES = KVB * VROWB;
+    extern __shared__ __attribute__((aligned(16))) char smem[];       // K ring [2][KBYTES] | V ring [2][VBYTES]
+    using V8 = typename Vec<T>::v8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, h2 = lane >> 5, l15 = lane & 15, g16 = lane >> 4;
+    const int nqb = p.Nq >> 8;
+    const int lin = xcd_remap(blockIdx.x, nqb * p.H * p.B);
+    const int qblk = lin % nqb, hb = lin / nqb;
+    const int h = hb % p.H, b = hb / p.H;
+    const int q0 = qblk * 256 + wave * 64;
+    const T* __restrict__ Qp = (const T*)p.Q + (long)b * p.Nq * p.ldq + h * D;
+    const T* Kp = (const T*)p.K + (long)b * p.Mk * p.ldk + h * D;
+    const T* Vp = (const T*)p.V + (long)b * p.Mk * p.ldv + h * D;
+    T* __restrict__ Op = (T*)p.O + (long)b * p.Nq * p.ldo + h * D;
+    const float c = p.scale * 1.44269504088896340736f;
+    const int nblk = p.Mk >> 6;
+
+    for (int i = tid; i < (2 * (KBYTES + VBYTES)) / 16; i += 256) *(uint4*)(smem + i * 16) = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    if (tid < 2 * KVB) {
+        *(T*)(smem + 2 * KBYTES + (tid >> 6) * VBYTES + (tid & 63) * VROWB + D * 2) = (T)1.0f;       // ones column of V at d = D: row D of O^T = softmax denominator
+        *(T*)(smem + (tid >> 6) * KBYTES + (tid & 63) * KROWB + D * 2) = (T)1.0f;                    // ones columns of K at d = D, D + 1: they meet the hi / lo
+        *(T*)(smem + (tid >> 6) * KBYTES + (tid & 63) * KROWB + D * 2 + 2) = (T)1.0f;                // halves of -m_ref in the Q fragment
+    }
+
+    // Q fragments (B operand of QK^T): lane holds q = l31, d = 16 ks + 8 h2 .. +7, pre-multiplied by scale * log2(e) unless that is 1;
+    // elements 0, 1 of qf[qt][2] on the h2 = 1 half (d = 40, 41) carry -m_ref
+    ap_i32x4 qf[2][3];
+    const bool unit = fabsf(c - 1.0f) < 1e-6f;
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const int q = q0 + qt * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) {
+            const int ch = 2 * ks + h2;
+            uint4 u = make_uint4(0, 0, 0, 0);
+            if (ch < DCH) u = *(const uint4*)(Qp + (long)q * p.ldq + ch * 8);
+            V8 v = as_v8<T>(u);
+            if (!unit) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] * c);
+            }
+            ap_i32x4 w = ap_bits(v);
+            asm volatile("" : "+a"(w));
+            qf[qt][ks] = w;
+        }
+    }
+
+    // ---- staging: 640 16-byte chunks per slot (K tile 320 + V tile 320) over 256 threads in three rounds; the tile a round moves is wave-uniform
+    //   round 0: K chunk tid;  round 1: wave 0: K chunk 256 + lane, waves 1-3: V chunk tid - 64;  round 2: waves 0, 1: V chunk tid + 192
+    const bool r1k = wave == 0;
+    const unsigned lds_base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+    unsigned gofs[3], lofs[2][3];                    // lofs[ring slot][round]: LDS byte addresses
+    {
+        // round 2 on waves 2, 3 (no chunks left) repeats V chunks tid - 128, which round 1 also wrote: same bytes, no branch in the slot
+        const int ck[3] = {tid, r1k ? 256 + tid : tid - 64, tid < 128 ? tid + 192 : tid - 128};
+        const bool isk[3] = {true, r1k, false};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int row = ck[i] / DCH, ch = ck[i] - row * DCH;
+            gofs[i] = (unsigned)((row * (isk[i] ? p.ldk : p.ldv) + ch * 8) * 2);
+            lofs[0][i] = lds_base + (unsigned)(isk[i] ? row * KROWB + ch * 16 : 2 * KBYTES + row * VROWB + ch * 16);
+            lofs[1][i] = lofs[0][i] + (isk[i] ? KBYTES : VBYTES);
+        }
+    }
+    const unsigned kstep = (unsigned)(KVB * p.ldk * 2), vstep = (unsigned)(KVB * p.ldv * 2);      // one batch of K / V is far below 4 GiB
+    uint4 rs0, rs1, rs2;
+    // tile indices are clamped to the last block: the tail slots re-stage it into ring slots nobody reads any more.  Buffer loads: the per-lane
+    // chunk offset in voffset, the tile's byte offset in soffset (SALU only)
+    const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1 = r1k ? rK : rV;
+    const unsigned step1 = r1k ? kstep : vstep;
+    auto gload1 = [&](int i, int kblk, int vblk) __attribute__((always_inline)) {
+        kblk = min(kblk, nblk - 1); vblk = min(vblk, nblk - 1);
+        const auto v = i == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rK, gofs[0], kblk * kstep, 0)
+                     : (i == 1 ? __builtin_amdgcn_raw_buffer_load_b128(r1, gofs[1], (r1k ? kblk : vblk) * step1, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rV, gofs[2], vblk * vstep, 0));
+        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
+        if (i == 0) rs0 = u; else if (i == 1) rs1 = u; else rs2 = u;
+    };
+    auto gload = [&](int kblk, int vblk) __attribute__((always_inline)) { gload1(0, kblk, vblk); gload1(1, kblk, vblk); gload1(2, kblk, vblk); };
+    // asm with an AGPR data operand: the staging loads then land in AGPRs (with a VGPR home hipcc spilled them to AGPRs right behind the load,
+    // i.e. vmcnt(0) three times per slot); hipcc still sees the load -> use dependency and places the vmcnt wait in front of the store
+    auto lstore1 = [&](int i, int slot) __attribute__((always_inline)) {
+        const ap_i32x4 w = ap_bits(i == 0 ? rs0 : (i == 1 ? rs1 : rs2));
+        asm volatile("ds_write_b128 %0, %1" :: "v"(lofs[slot][i]), "a"(w) : "memory");
+    };
+    auto lstore = [&](int slot) __attribute__((always_inline)) { lstore1(0, slot); lstore1(1, slot); lstore1(2, slot); };
+    // K fragments (A operand of the asm QK^T MFMAs: AGPRs) and V^T fragments (A operand of the builtin PV MFMAs: either class) are read by
+    // builtins, so hipcc places the lgkmcnt waits.  (Asm reads with AGPR outputs were tried: the two 64-bit halves of a V^T fragment are glued by
+    // a REG_SEQUENCE, and hipcc copied them — before the data had arrived, which it cannot know — so that form is unsafe.)
+    V8 kf[3][2];
+    auto kread1 = [&](int ks, int kt, int slot) __attribute__((always_inline)) {
+        kf[ks][kt] = as_v8<T>(*(const uint4*)(smem + slot * KBYTES + (kt * 32 + l31) * KROWB + (2 * ks + h2) * 16));
+    };
+    auto kread = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int ks = 0; ks < 3; ++ks) { kread1(ks, 0, slot); kread1(ks, 1, slot); }
+    };
+    V8 vfA[4][2], vfB[4][2];                         // V^T fragments of blocks t - 1 (in use) and t (being read)
+    auto vread1 = [&](V8 (&vf)[4][2], int st, int dt, int slot) __attribute__((always_inline)) {
+        const char* vp = smem + 2 * KBYTES + slot * VBYTES + (16 * st + 4 * (g16 >> 1) + (l15 >> 2)) * VROWB + (dt * 32 + 16 * (g16 & 1) + (l15 & 3) * 4) * 2;
+        vf[st][dt] = __builtin_bit_cast(V8, __builtin_shufflevector(ap_lds_read_tr16(vp), ap_lds_read_tr16(vp + 8 * VROWB), 0, 1, 2, 3));
+    };
+
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 o[2][2];                                  // [q tile][d tile of 32], pinned to a[32 qt + 16 dt ..]
+    o[0][0] = zero16; o[0][1] = zero16; o[1][0] = zero16; o[1][1] = zero16;
+    float mref[2] = {0.f, 0.f};                      // integer-valued
+    f32x16 sA[2][2], sB[2][2];                       // S' = s - m_ref of blocks t (even t: sA) and t + 1
+    ap_i32x4 pA[2][4], pB[2][4];                     // P^T of blocks t - 1 and t (B operand of PV), packed 16-bit pairs
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt)
+#pragma unroll
+        for (int st = 0; st < 4; ++st) { pA[qt][st] = (ap_i32x4){0, 0, 0, 0}; pB[qt][st] = pA[qt][st]; }
+#pragma unroll
+    for (int st = 0; st < 4; ++st) { vfA[st][0] = as_v8<T>(make_uint4(0, 0, 0, 0)); vfA[st][1] = vfA[st][0]; vfB[st][0] = vfA[st][0]; vfB[st][1] = vfA[st][0]; }
+
+    // matrix work of a slot, one MFMA per call: QK^T i in [0, 12): (ks, kt, qt) = (i >> 2, (i >> 1) & 1, i & 1); PV j in [0, 16): (st, dt, qt)
+    auto qk1 = [&](auto I, f32x16 (&s)[2][2]) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value, ks = i >> 2, kt = (i >> 1) & 1, qt = i & 1;
+        if constexpr (ks == 0) ap_sacc0<T>(s[kt][qt], ap_bits(kf[0][kt]), qf[qt][0]);
+        else if constexpr (ks == 1) ap_sacc<T>(s[kt][qt], ap_bits(kf[1][kt]), qf[qt][1]);
+        else ap_sacc_ref<T, qt>(s[kt][qt], ap_bits(kf[2][kt]), qf[qt][2]);
+    };
+    auto pv1 = [&](auto J, ap_i32x4 (&pf)[2][4], V8 (&vf)[4][2]) __attribute__((always_inline)) {
+        constexpr int j = decltype(J)::value, st = j >> 2, dt = (j >> 1) & 1, qt = j & 1;
+        o[qt][dt] = mfma32(vf[st][dt], __builtin_bit_cast(V8, pf[qt][st]), o[qt][dt]);
+    };
+    // softmax piece k in [0, 32): dword k of P(t): (qt, st, w) = (k >> 4, (k >> 2) & 3, k & 3) = elements 2 w, 2 w + 1 of pf[qt][st], from
+    // S' registers 8 (st & 1) + 2 w (+1) of tile (st >> 1, qt); its pack is issued with piece k + 1 (ap_piece), the last one by ap_pack
+    float ex[3] = {0.f, 0.f, 0.f}, ey[3] = {0.f, 0.f, 0.f};      // results of the pieces in flight: pair k % 3 (the pack trails by two pieces, see ap_piece)
+    auto piece = [&](auto K, const f32x16 (&s)[2][2], ap_i32x4 (&pf)[2][4]) __attribute__((always_inline)) {
+        constexpr int k = decltype(K)::value, qt = k >> 4, st = (k >> 2) & 3, w = k & 3;
+        const float a = s[st >> 1][qt][8 * (st & 1) + 2 * w], bb = s[st >> 1][qt][8 * (st & 1) + 2 * w + 1];
+        if constexpr (k < 2) ap_piece0(a, bb, ex[k], ey[k]);
+        else { constexpr int j = k - 2; pf[j >> 4][(j >> 2) & 3][j & 3] = ap_piece<T>(a, bb, ex[k % 3], ey[k % 3], ex[j % 3], ey[j % 3]); }
+    };
+    // maximum of S'(t+1): block m in [0, 8): (qt, kt, half) = (m >> 2, (m >> 1) & 1, m & 1), eight registers each
+    float mx[8];
+    auto maxblk = [&](auto M, const f32x16 (&s)[2][2]) __attribute__((always_inline)) {
+        constexpr int m = decltype(M)::value, qt = m >> 2, kt = (m >> 1) & 1, r0 = 8 * (m & 1);
+        const f32x16& v = s[kt][qt];
+        mx[m] = ap_max8(v[r0], v[r0 + 1], v[r0 + 2], v[r0 + 3], v[r0 + 4], v[r0 + 5], v[r0 + 6], v[r0 + 7]);
+    };
+    auto bmax = [&](int qt) __attribute__((always_inline)) -> float {
+        const float m = ap_max4(mx[4 * qt], mx[4 * qt + 1], mx[4 * qt + 2], mx[4 * qt + 3]);
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        return ap_max2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+    };
+    // set the (integer) reference of q tile qt: -m_ref = -(hi + lo), hi a multiple of `split`, both exact in T
+    const unsigned long long upper_half = 0xffffffff00000000ull;
+    auto set_ref = [&](auto QT, float mnew) __attribute__((always_inline)) {
+        constexpr int qt = decltype(QT)::value;
+        mref[qt] = mnew;
+        const float hi = truncf(mnew * (1.0f / ApT<T>::split)) * (float)ApT<T>::split, lo = mnew - hi;
+        const T nh = (T)(-hi), nl = (T)(-lo);
+        const unsigned bits = (unsigned)__builtin_bit_cast(unsigned short, nh) | ((unsigned)__builtin_bit_cast(unsigned short, nl) << 16);
+        ap_i32x4 w = qf[qt][2];
+        w[0] = h2 ? (int)bits : w[0];
+        asm volatile("" : "+a"(w));                // the fragment's home stays an AGPR tuple (a VGPR home is copied over before every MFMA)
+        qf[qt][2] = w;
+    };
+
+    // ---- prologue: K(0), K(1), V(0) staged; S(0) against m_ref = 0; m_ref := ceil(maximum of block 0); K(1) fragments in registers, K(2) in ring slot 0
+    gload(0, 0); __syncthreads(); lstore(0);
+    gload(1, 0); lstore(1);                          // (V(0) goes to both V ring slots: a staging round always moves both tiles)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    kread(0);
+    ap_for(ap_range<0, 12>(), [&](auto I) __attribute__((always_inline)) { qk1(I, sA); });
+    kread(1);
+    gload(2, 0);
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs' results settle before the VALU reads them
+    __syncthreads();                                 // every wave has read K(0) from ring slot 0
+    lstore(0);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+    ap_for(ap_range<0, 2>(), [&](auto QT) __attribute__((always_inline)) {
+        constexpr int qt = decltype(QT)::value;
+        float m = sA[0][qt][0];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m = fmaxf(m, fmaxf(sA[0][qt][r], sA[1][qt][r]));
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(m), __float_as_uint(m), false, false);
+        m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
+        const float mr = fminf(fmaxf(ceilf(m), -60000.f), 60000.f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { sA[0][qt][r] -= mr; sA[1][qt][r] -= mr; }
+        set_ref(QT, mr);
+    });
+
+    // ---- slot t.  Matrix pipe: QK^T(t+1) (gaps 0-11), PV(t-1) (gaps 12-27).  VALU: S'(t) -> P(t) (32 pieces), maximum of S'(t+1) (gaps 16-25).
+    // One barrier between the two matrix phases: tiles stored in the second half of slot t - 1 become readable behind it (K(t+2) fragments right
+    // after it, V(t) fragments later), and this slot's stores overwrite ring slots whose last readers (second half of slot t - 1) every wave has
+    // passed before it arrives.  Raw s_barrier + lgkmcnt(0) only: the staging loads issued at the top of the slot stay in flight across it.
+    auto slot = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], ap_i32x4 (&pp)[2][4], ap_i32x4 (&pc)[2][4], V8 (&vfc)[4][2], V8 (&vfn)[4][2], auto PAR) __attribute__((always_inline)) {
+        constexpr int par = decltype(PAR)::value;    // t & 1: ring slots are compile-time constants
+        __builtin_amdgcn_sched_barrier(0);
+        ap_for(ap_range<0, 12>(), [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            qk1(I, sn);
+            if constexpr (i < 3) gload1(i, t + 3, t + 1);
+            // pieces 0 .. 17: two in even gaps, one in odd gaps
+            constexpr int k0 = 3 * (i >> 1) + 2 * (i & 1);
+            piece(ap_ic<k0>{}, sc, pc);
+            if constexpr (!(i & 1)) piece(ap_ic<k0 + 1>{}, sc, pc);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        float bm0 = 0.f, bm1 = 0.f;
+        ap_for(ap_range<12, 28>(), [&](auto I) __attribute__((always_inline)) {
+            constexpr int i = decltype(I)::value;
+            pv1(ap_ic<i - 12>{}, pp, vfc);           // P(t-1) x V(t-1)
+            if constexpr (i < 20) vread1(vfn, (i - 12) >> 1, (i - 12) & 1, par);                             // V(t), staged in slot t - 1, into the other fragment set
+            if constexpr (i >= 18 && i < 24) kread1((i - 18) >> 1, (i - 18) & 1, par);                       // K(t+2), staged in slot t - 1 (this slot's QK^T MFMAs are issued)
+            if constexpr (i == 19 || i == 21 || i == 23) lstore1((i - 19) >> 1, par ^ 1);                    // K(t+3), V(t+1)
+            // pieces 18 .. 23 in gaps 12-15 (2, 1, 2, 1); 24 .. 27 in gaps 16, 18, 20, 22; 28 .. 31 in gaps 24-27
+            if constexpr (i < 16) { constexpr int k0 = 18 + 3 * ((i - 12) >> 1) + 2 * (i & 1); piece(ap_ic<k0>{}, sc, pc); if constexpr (!(i & 1)) piece(ap_ic<k0 + 1>{}, sc, pc); }
+            else if constexpr (i < 24) { if constexpr (!(i & 1)) piece(ap_ic<24 + ((i - 16) >> 1)>{}, sc, pc); }
+            else piece(ap_ic<28 + (i - 24)>{}, sc, pc);
+            if constexpr (i >= 16 && i < 24) maxblk(ap_ic<i - 16>{}, sn);                          // S'(t+1): its last MFMA issued in gap 11
+            if constexpr (i == 24) bm0 = bmax(0);
+            if constexpr (i == 25) bm1 = bmax(1);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        pc[1][3][2] = ap_pack<T>(ex[30 % 3], ey[30 % 3]);      // packs of pieces 30, 31
+        pc[1][3][3] = ap_pack<T>(ex[31 % 3], ey[31 % 3]);
+        // rare path: some query's S'(t+1) exceeds thr: raise its reference by the integer dl BEFORE the exponentials of block t + 1 are taken
+        if (__builtin_amdgcn_ballot_w64(fmaxf(bm0, bm1) > thr) != 0) {
+            asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // PV(t-1) has landed in O
+            ap_for(ap_range<0, 2>(), [&](auto QT) __attribute__((always_inline)) {
+                constexpr int qt = decltype(QT)::value;
+                const float mnew = fminf(mref[qt] + fmaxf(ceilf(qt ? bm1 : bm0), 0.f), 60000.f);
+                const float dl = mnew - mref[qt];                                // integer >= 0
+                { const float al = __builtin_amdgcn_exp2f(-dl); o[qt][0] = o[qt][0] * al; o[qt][1] = o[qt][1] * al; asm volatile("" : "+a"(o[qt][0])); asm volatile("" : "+a"(o[qt][1])); }
+                const unsigned de = (unsigned)fminf(dl, (float)ApT<T>::maxdl) << ApT<T>::expsh;
+                const unsigned de2 = de | (de << 16);
+#pragma unroll
+                for (int st = 0; st < 4; ++st)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(pc[qt][st][w]) : "v"(de2));      // P(t) *= 2^-dl (exponent field, saturating at 0)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { sn[0][qt][r] -= dl; sn[1][qt][r] -= dl; }
+                set_ref(QT, mnew);
+            });
+        }
+    };
+    for (int t = 0; t < nblk; t += 2) {
+        slot(t, sA, sB, pA, pB, vfA, vfB, ap_ic<0>{});
+        slot(t + 1, sB, sA, pB, pA, vfB, vfA, ap_ic<1>{});
+    }
+    ap_for(ap_range<0, 16>(), [&](auto J) __attribute__((always_inline)) { pv1(J, pA, vfA); });      // P(nblk-1) (nblk even: written by the odd slot into pA) x V(nblk-1)
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
+
+    // ---- finalize: l from row D of O^T (ones column), normalise, store
+#pragma unroll
+    for (int qt = 0; qt < 2; ++qt) {
+        const float mine = (h2 == 0) ? o[qt][1][4] : 0.f;          // d = 40: tile 1, row 8 = register 4 of the h2 = 0 half
+        auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(mine), __float_as_uint(mine), false, false);
+        const float l = __uint_as_float(sw[0]) + __uint_as_float(sw[1]);
+        const float inv = (l > 0.f) ? 1.0f / l : 0.f;
+        const int q = q0 + qt * 32 + l31;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+            for (int rq = 0; rq < 4; ++rq) {
+                const int d = dt * 32 + 8 * rq + 4 * h2;
+                if (d < D)
+                    *(uint2*)(Op + (long)q * p.ldo + d) = pack4<T>(o[qt][dt][4 * rq] * inv, o[qt][dt][4 * rq + 1] * inv, o[qt][dt][4 * rq + 2] * inv, o[qt][dt][4 * rq + 3] * inv);
+            }
+    }
+}
+
+bool attn_pipe_ok(const AttnArgs& a) {
+    return a.D == 40 && !a.causal && !a.bias && !a.O8 && a.Nq % 256 == 0 && a.Mk % 128 == 0 && a.Mk >= 256 &&
+           a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0;
+}
+
+template <typename T>
+static void launch_attn40p(const AttnArgs& a, hipStream_t s, float thr) {
+    const size_t lds = 2 * 64 * (144 + 192);
+    dim3 grid((a.Nq / 256) * a.H * a.B);
+    hipLaunchKernelGGL((attn40p_kernel<T>), grid, dim3(256), lds, s, a, thr);
+}
+
+// thr_override: NaN = the type's default (tests force the rare path with a small or negative value)
+void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override) {
+    if (dt == DT_BF16) launch_attn40p<__bf16>(a, s, thr_override == thr_override ? thr_override : ApT<__bf16>::thr);
+    else launch_attn40p<_Float16>(a, s, thr_override == thr_override ? fminf(thr_override, ApT<_Float16>::thr) : ApT<_Float16>::thr);
+}
+
+}  // namespace ldx

@@ -119,6 +119,10 @@ struct AttnArgs {
     void* O8; int ldo8; uint32_t* SO; int so_ld;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+// Software-pipelined D = 40 kernel (attn_pipe.hip, round 4): attn_pipe_ok() says whether it takes the shape (D = 40, Nq % 256 == 0, Mk % 128 == 0,
+// Mk >= 256, no mask / bias); thr_override = NaN keeps the type's rescale threshold (tests force the rare path with small values).
+bool attn_pipe_ok(const AttnArgs& a);
+void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 
 // Cross-attention sub-block as one kernel (xattn_block.hip): H[m][:] += to_out(softmax(to_q(LayerNorm(H[m][:])) . K_b^T) . V_b) + bo, in place,
 // for m in [0, M), image b = m / N.  Wq / Wo: [C][C] 16-bit, row = output feature.  K / V: the projected context, rows b * Mk + key, head h at

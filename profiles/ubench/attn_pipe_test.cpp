@@ -1,0 +1,128 @@
+// Stand-alone check + A/B timing of the D = 40 attention kernels through the C ABI (no torch: a gpurun call spends its time on the GPU).
+//   build:  hipcc -O2 -std=c++17 profiles/ubench/attn_pipe_test.cpp -o profiles/ubench/attn_pipe_test -L lightdiffusion-next_amd -lldx -Wl,-rpath,'$ORIGIN/../../lightdiffusion-next_amd'
+//   run  :  profiles/ubench/attn_pipe_test [N_big] [reps]
+// 1. B1 H2 N512 (and N = 1024 with a score spike) against a double-precision reference on the rounded inputs, for attn32* (LDX_ATTN_PIPE=0), the
+//    pipelined kernel, and the pipelined kernel with the rescale path forced on every block (LDX_ATTN_PIPE_THR=-1000) or often (THR=0).
+// 2. B2 H8 N16384 D40 timing, the two kernels alternating, HIP events on the launch stream.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <random>
+#include <vector>
+#include "../../include/ldx.h"
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e_), __FILE__, __LINE__); exit(1); } } while (0)
+
+static uint16_t f2bf(float f) { uint32_t u; memcpy(&u, &f, 4); u += 0x7fff + ((u >> 16) & 1); return (uint16_t)(u >> 16); }
+static float bf2f(uint16_t h) { uint32_t u = (uint32_t)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+struct Prob { int B, H, N, D, ld; std::vector<uint16_t> qkv; std::vector<uint16_t> out; };
+
+static void reference(const Prob& p, float scale, std::vector<double>& ref) {
+    const int C = p.H * p.D;
+    ref.assign((size_t)p.B * p.N * C, 0.0);
+    std::vector<double> s(p.N);
+    for (int b = 0; b < p.B; ++b) for (int h = 0; h < p.H; ++h) for (int i = 0; i < p.N; ++i) {
+        const uint16_t* q = &p.qkv[((size_t)b * p.N + i) * p.ld + h * p.D];
+        double mx = -1e300;
+        for (int j = 0; j < p.N; ++j) {
+            const uint16_t* k = &p.qkv[((size_t)b * p.N + j) * p.ld + C + h * p.D];
+            double a = 0; for (int d = 0; d < p.D; ++d) a += (double)bf2f(q[d]) * bf2f(k[d]);
+            s[j] = a * scale; mx = std::max(mx, s[j]);
+        }
+        double l = 0; for (int j = 0; j < p.N; ++j) { s[j] = std::exp(s[j] - mx); l += s[j]; }
+        double* o = &ref[((size_t)b * p.N + i) * C + h * p.D];
+        for (int j = 0; j < p.N; ++j) {
+            const uint16_t* v = &p.qkv[((size_t)b * p.N + j) * p.ld + 2 * C + h * p.D];
+            const double w = s[j] / l;
+            for (int d = 0; d < p.D; ++d) o[d] += w * bf2f(v[d]);
+        }
+    }
+}
+
+static void run(const Prob& p, float scale, void* dq, void* dout, hipStream_t st) {
+    const int C = p.H * p.D;
+    const uint16_t* base = (const uint16_t*)dq;
+    int rc = ldx_op_attention(base, p.ld, base + C, p.ld, base + 2 * C, p.ld, dout, C, p.B, p.H, p.N, p.N, p.D, scale, 0, 0 /* bf16 */, st);
+    if (rc) { printf("ldx_op_attention rc=%d\n", rc); exit(1); }
+}
+
+static void compare(const char* tag, const Prob& p, const std::vector<double>& ref, const std::vector<uint16_t>& out) {
+    double num = 0, den = 0, mxe = 0; size_t bad = 0;
+    for (size_t i = 0; i < ref.size(); ++i) {
+        const double o = bf2f(out[i]), e = o - ref[i];
+        if (!(o == o) || std::isinf(o)) ++bad;
+        num += e * e; den += ref[i] * ref[i]; mxe = std::max(mxe, std::fabs(e));
+    }
+    printf("  %-34s rel-L2 %.3e  max|err| %.3e  nonfinite %zu\n", tag, std::sqrt(num / den), mxe, bad);
+}
+
+int main(int argc, char** argv) {
+    const int NBIG = argc > 1 ? atoi(argv[1]) : 16384, reps = argc > 2 ? atoi(argv[2]) : 20;
+    hipStream_t st; CK(hipStreamCreate(&st));
+    setenv("LDX_ATTN_PIPE_MINWG", "1", 1);
+    std::mt19937 rng(1234);
+    std::normal_distribution<float> nd(0.f, 1.f);
+    for (int test = 0; test < 3; ++test) {
+        Prob p; p.B = 1; p.H = 2; p.D = 40; p.N = test == 0 ? 512 : 1024; p.ld = 3 * p.H * p.D;
+        const int C = p.H * p.D;
+        p.qkv.resize((size_t)p.B * p.N * p.ld);
+        const float amp = test == 2 ? 4.0f : 1.5f;
+        for (auto& x : p.qkv) x = f2bf(nd(rng) * amp);
+        if (test >= 1) {       // score spikes: a few late keys line up with the queries' mean direction, so the running maximum jumps mid-sequence
+            for (int j : {400, 401, 777, 1000})
+                for (int h = 0; h < p.H; ++h) for (int d = 0; d < p.D; ++d) p.qkv[(size_t)j * p.ld + C + h * p.D + d] = f2bf((d % 3 == 0 ? 6.0f : -5.0f) * (test == 2 ? 3.0f : 1.0f));
+            for (int i = 0; i < p.N; i += 3)
+                for (int h = 0; h < p.H; ++h) for (int d = 0; d < p.D; ++d) p.qkv[(size_t)i * p.ld + h * p.D + d] = f2bf((d % 3 == 0 ? 2.0f : -1.5f) + nd(rng) * 0.3f);
+        }
+        const float scale = (test == 2) ? 1.0f / 1.44269504088896340736f : 1.0f / std::sqrt(40.0f);      // test 2: the engine's calling convention (c = 1)
+        std::vector<double> ref; reference(p, scale, ref);
+        void *dq, *dout; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout, (size_t)p.B * p.N * C * 2));
+        CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
+        printf("test %d: B%d H%d N%d D%d scale %.4f\n", test, p.B, p.H, p.N, p.D, scale);
+        struct { const char* tag; const char* pipe; const char* thr; } cfg[] = {
+            {"attn32 (LDX_ATTN_PIPE=0)", "0", nullptr}, {"pipelined, default threshold", "1", nullptr},
+            {"pipelined, THR=0", "1", "0"}, {"pipelined, THR=-1000 (every block)", "1", "-1000"}, {"pipelined, THR=3", "1", "3"}};
+        for (auto& c : cfg) {
+            setenv("LDX_ATTN_PIPE", c.pipe, 1);
+            if (c.thr) setenv("LDX_ATTN_PIPE_THR", c.thr, 1); else unsetenv("LDX_ATTN_PIPE_THR");
+            CK(hipMemset(dout, 0xff, (size_t)p.B * p.N * C * 2));
+            run(p, scale, dq, dout, st); CK(hipStreamSynchronize(st));
+            std::vector<uint16_t> out((size_t)p.B * p.N * C);
+            CK(hipMemcpy(out.data(), dout, out.size() * 2, hipMemcpyDeviceToHost));
+            compare(c.tag, p, ref, out);
+        }
+        unsetenv("LDX_ATTN_PIPE_THR");
+        CK(hipFree(dq)); CK(hipFree(dout));
+    }
+    // ---- timing
+    {
+        Prob p; p.B = 2; p.H = 8; p.D = 40; p.N = NBIG; p.ld = 3 * p.H * p.D;
+        const int C = p.H * p.D;
+        p.qkv.resize((size_t)p.B * p.N * p.ld);
+        for (auto& x : p.qkv) x = f2bf(nd(rng));
+        void *dq, *dout0, *dout1; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout0, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout1, (size_t)p.B * p.N * C * 2));
+        CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
+        const float scale = 1.0f / 1.44269504088896340736f / std::sqrt(40.0f) * 3.0f;
+        hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        const double flop = 4.0 * p.B * p.H * (double)p.N * p.N * p.D;
+        for (int round = 0; round < 3; ++round)
+            for (int which = 0; which < 2; ++which) {
+                setenv("LDX_ATTN_PIPE", which ? "1" : "0", 1);
+                void* o = which ? dout1 : dout0;
+                for (int i = 0; i < 3; ++i) run(p, scale, dq, o, st);
+                CK(hipEventRecord(e0, st));
+                for (int i = 0; i < reps; ++i) run(p, scale, dq, o, st);
+                CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
+                float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+                printf("timing N%d round %d %-10s %.1f us / launch  %.0f TFLOP/s (%.3f of 2.5 PF)\n", p.N, round, which ? "pipelined" : "attn32*", ms * 1e3 / reps, flop / (ms / reps * 1e-3) * 1e-12, flop / (ms / reps * 1e-3) / 2.5e15);
+            }
+        std::vector<uint16_t> a((size_t)p.B * p.N * C), b(a.size());
+        CK(hipMemcpy(a.data(), dout0, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), dout1, b.size() * 2, hipMemcpyDeviceToHost));
+        double num = 0, den = 0; for (size_t i = 0; i < a.size(); ++i) { const double x = bf2f(a[i]), y = bf2f(b[i]); num += (x - y) * (x - y); den += x * x; }
+        printf("big problem: pipelined vs attn32* rel-L2 %.3e\n", std::sqrt(num / den));
+    }
+    return 0;
+}
