@@ -50,8 +50,7 @@ template <typename T> struct ApT;
 template <> struct ApT<__bf16>   { static constexpr int split = 256, expsh = 7, maxdl = 255; static constexpr float thr = 32.0f; };
 template <> struct ApT<_Float16> { static constexpr int split = 2048, expsh = 10, maxdl = 31; static constexpr float thr = 15.0f; };
 
-// ---- 32x32x16 MFMAs with explicit register classes.  S' chains: first (C = 0), middle, last (its Q operand is the pinned reference-carrying
-// fragment of q tile QT: a[64:67] / a[68:71]); O^T chains: tile (qt, dt) pinned to a[32 qt + 16 dt .. +15].
+// ---- QK^T MFMAs (32x32x16) with explicit register classes: S' in arch VGPRs, K / Q fragments in AGPRs.  First MFMA of a chain: C = 0.
 #define AP_BF16 "v_mfma_f32_32x32x16_bf16"
 #define AP_F16 "v_mfma_f32_32x32x16_f16"
 template <typename T> __device__ __forceinline__ void ap_sacc0(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
@@ -61,41 +60,6 @@ template <typename T> __device__ __forceinline__ void ap_sacc0(f32x16& d, ap_i32
 template <typename T> __device__ __forceinline__ void ap_sacc(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
     if constexpr (std::is_same<T, __bf16>::value) asm volatile(AP_BF16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
     else asm volatile(AP_F16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
-}
-template <typename T, int QT> __device__ __forceinline__ void ap_sacc_ref(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
-    if constexpr (std::is_same<T, __bf16>::value) {
-        asm volatile(AP_BF16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
-    } else {
-        asm volatile(AP_F16 " %0, %1, %2, %0" : "+v"(d) : "a"(a), "a"(b));
-    }
-}
-#define AP_OACC(OPC, CONS) asm volatile(OPC " %0, %1, %2, %0" : CONS(d) : "a"(a), "v"(b))
-template <typename T, int QD> __device__ __forceinline__ void ap_oacc(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
-    if constexpr (std::is_same<T, __bf16>::value) {
-        AP_OACC(AP_BF16, "+a");
-    } else {
-        AP_OACC(AP_F16, "+a");
-    }
-}
-// ---- rare path pieces on the pinned registers
-#define AP_RS1(r) "v_accvgpr_read_b32 %1, a" #r "\n\tv_mul_f32 %1, %1, %2\n\tv_accvgpr_write_b32 a" #r ", %1\n\t"
-#define AP_RS16(a0, a1, a2, a3, a4, a5, a6, a7, a8, a9, a10, a11, a12, a13, a14, a15) \
-    AP_RS1(a0) AP_RS1(a1) AP_RS1(a2) AP_RS1(a3) AP_RS1(a4) AP_RS1(a5) AP_RS1(a6) AP_RS1(a7) AP_RS1(a8) AP_RS1(a9) AP_RS1(a10) AP_RS1(a11) AP_RS1(a12) AP_RS1(a13) AP_RS1(a14) AP_RS1(a15)
-template <int QT> __device__ __forceinline__ void ap_rescale(f32x16& o0, f32x16& o1, float al) {       // both d tiles of q tile QT *= al
-    float t;
-    if constexpr (QT == 0) {
-        asm volatile(AP_RS16(0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15) "s_nop 1" : "+{a[0:15]}"(o0), "=&v"(t) : "v"(al));
-        asm volatile(AP_RS16(16, 17, 18, 19, 20, 21, 22, 23, 24, 25, 26, 27, 28, 29, 30, 31) "s_nop 1" : "+{a[16:31]}"(o1), "=&v"(t) : "v"(al));
-    } else {
-        asm volatile(AP_RS16(32, 33, 34, 35, 36, 37, 38, 39, 40, 41, 42, 43, 44, 45, 46, 47) "s_nop 1" : "+{a[32:47]}"(o0), "=&v"(t) : "v"(al));
-        asm volatile(AP_RS16(48, 49, 50, 51, 52, 53, 54, 55, 56, 57, 58, 59, 60, 61, 62, 63) "s_nop 1" : "+{a[48:63]}"(o1), "=&v"(t) : "v"(al));
-    }
-}
-// dword 0 of the pinned Q fragment of q tile QT := refbits on the lanes of mask (the h2 = 1 half: elements 0, 1 = d 40, 41)
-template <int QT> __device__ __forceinline__ void ap_setref(ap_i32x4& q2, unsigned refbits, unsigned long long mask) {
-    unsigned t;
-    if constexpr (QT == 0) asm volatile("v_accvgpr_read_b32 %1, a64\n\tv_cndmask_b32_e64 %1, %1, %2, %3\n\tv_accvgpr_write_b32 a64, %1\n\ts_nop 3" : "+{a[64:67]}"(q2), "=&v"(t) : "v"(refbits), "s"(mask));
-    else asm volatile("v_accvgpr_read_b32 %1, a68\n\tv_cndmask_b32_e64 %1, %1, %2, %3\n\tv_accvgpr_write_b32 a68, %1\n\ts_nop 3" : "+{a[68:71]}"(q2), "=&v"(t) : "v"(refbits), "s"(mask));
 }
 // ---- softmax pieces.  Piece k: exp2 of element a, the pack of piece k - 2's results (px, py -> one dword of P), exp2 of element b.  A VALU read of a
 // fresh transcendental result needs a wait state; hipcc cannot see the order inside an asm block and pads every block whose inputs were written by
@@ -241,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     };
 
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    f32x16 o[2][2];                                  // [q tile][d tile of 32], pinned to a[32 qt + 16 dt ..]
+    f32x16 o[2][2];                                  // [q tile][d tile of 32]; only the matrix pipe touches it in the loop: hipcc keeps it in AGPRs
     o[0][0] = zero16; o[0][1] = zero16; o[1][0] = zero16; o[1][1] = zero16;
     float mref[2] = {0.f, 0.f};                      // integer-valued
     f32x16 sA[2][2], sB[2][2];                       // S' = s - m_ref of blocks t (even t: sA) and t + 1
@@ -258,7 +222,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         constexpr int i = decltype(I)::value, ks = i >> 2, kt = (i >> 1) & 1, qt = i & 1;
         if constexpr (ks == 0) ap_sacc0<T>(s[kt][qt], ap_bits(kf[0][kt]), qf[qt][0]);
         else if constexpr (ks == 1) ap_sacc<T>(s[kt][qt], ap_bits(kf[1][kt]), qf[qt][1]);
-        else ap_sacc_ref<T, qt>(s[kt][qt], ap_bits(kf[2][kt]), qf[qt][2]);
+        else ap_sacc<T>(s[kt][qt], ap_bits(kf[2][kt]), qf[qt][2]);
     };
     auto pv1 = [&](auto J, ap_i32x4 (&pf)[2][4], V8 (&vf)[4][2]) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value, st = j >> 2, dt = (j >> 1) & 1, qt = j & 1;
@@ -286,7 +250,6 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         return ap_max2(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
     };
     // set the (integer) reference of q tile qt: -m_ref = -(hi + lo), hi a multiple of `split`, both exact in T
-    const unsigned long long upper_half = 0xffffffff00000000ull;
     auto set_ref = [&](auto QT, float mnew) __attribute__((always_inline)) {
         constexpr int qt = decltype(QT)::value;
         mref[qt] = mnew;
@@ -411,6 +374,10 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     }
 }
 
+// Measured and NOT kept (profiles/ubench/README.md round 4): the same pipeline at two waves per SIMD (eight waves x 32 queries, <= 256 registers, plain
+// builtins): 863 us against 835 with QK^T / PV as phases, 963 us with the two MFMA kinds interleaved into four accumulator chains per wave — the two
+// waves of a SIMD share its VALU issue port and matrix pipe, and what one gains the other loses.
+
 bool attn_pipe_ok(const AttnArgs& a) {
     return a.D == 40 && !a.causal && !a.bias && !a.O8 && a.Nq % 256 == 0 && a.Mk % 128 == 0 && a.Mk >= 256 &&
            a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0;
@@ -423,10 +390,11 @@ static void launch_attn40p(const AttnArgs& a, hipStream_t s, float thr) {
     hipLaunchKernelGGL((attn40p_kernel<T>), grid, dim3(256), lds, s, a, thr);
 }
 
-// thr_override: NaN = the type's default (tests force the rare path with a small or negative value)
+// thr_override: NaN = the type's default (tests force the rare path with small values)
 void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override) {
-    if (dt == DT_BF16) launch_attn40p<__bf16>(a, s, thr_override == thr_override ? thr_override : ApT<__bf16>::thr);
-    else launch_attn40p<_Float16>(a, s, thr_override == thr_override ? fminf(thr_override, ApT<_Float16>::thr) : ApT<_Float16>::thr);
+    const bool ov = thr_override == thr_override;
+    if (dt == DT_BF16) launch_attn40p<__bf16>(a, s, ov ? thr_override : ApT<__bf16>::thr);
+    else launch_attn40p<_Float16>(a, s, ov ? fminf(thr_override, ApT<_Float16>::thr) : ApT<_Float16>::thr);
 }
 
 }  // namespace ldx

@@ -65,7 +65,8 @@ int main(int argc, char** argv) {
     setenv("LDX_ATTN_PIPE_MINWG", "1", 1);
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
-    for (int test = 0; test < 3; ++test) {
+    const int only = argc > 3 ? atoi(argv[3]) : -1;      // >= 0: skip the parity part and time only that variant (PMC runs)
+    for (int test = 0; test < (only >= 0 ? 0 : 3); ++test) {
         Prob p; p.B = 1; p.H = 2; p.D = 40; p.N = test == 0 ? 512 : 1024; p.ld = 3 * p.H * p.D;
         const int C = p.H * p.D;
         p.qkv.resize((size_t)p.B * p.N * p.ld);
@@ -83,8 +84,9 @@ int main(int argc, char** argv) {
         CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
         printf("test %d: B%d H%d N%d D%d scale %.4f\n", test, p.B, p.H, p.N, p.D, scale);
         struct { const char* tag; const char* pipe; const char* thr; } cfg[] = {
-            {"attn32 (LDX_ATTN_PIPE=0)", "0", nullptr}, {"pipelined, default threshold", "1", nullptr},
-            {"pipelined, THR=0", "1", "0"}, {"pipelined, THR=-1000 (every block)", "1", "-1000"}, {"pipelined, THR=3", "1", "3"}};
+            {"attn32 (LDX_ATTN_PIPE=0)", "0", nullptr}, {"pipe 4w, default threshold", "1", nullptr},
+            {"pipe 4w, THR=0", "1", "0"}, {"pipe 4w, THR=3", "1", "3"},
+            {"pipe 8w, default threshold", "2", nullptr}, {"pipe 8w, THR=0", "2", "0"}, {"pipe 8w, THR=3", "2", "3"}};
         for (auto& c : cfg) {
             setenv("LDX_ATTN_PIPE", c.pipe, 1);
             if (c.thr) setenv("LDX_ATTN_PIPE_THR", c.thr, 1); else unsetenv("LDX_ATTN_PIPE_THR");
@@ -103,26 +105,30 @@ int main(int argc, char** argv) {
         const int C = p.H * p.D;
         p.qkv.resize((size_t)p.B * p.N * p.ld);
         for (auto& x : p.qkv) x = f2bf(nd(rng));
-        void *dq, *dout0, *dout1; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout0, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout1, (size_t)p.B * p.N * C * 2));
+        void *dq, *dout0, *dout1, *dout2; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout0, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout1, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout2, (size_t)p.B * p.N * C * 2));
         CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
         const float scale = 1.0f / 1.44269504088896340736f / std::sqrt(40.0f) * 3.0f;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const double flop = 4.0 * p.B * p.H * (double)p.N * p.N * p.D;
         for (int round = 0; round < 3; ++round)
-            for (int which = 0; which < 2; ++which) {
-                setenv("LDX_ATTN_PIPE", which ? "1" : "0", 1);
-                void* o = which ? dout1 : dout0;
+            for (int which = 0; which < 3; ++which) {
+                if (only >= 0 && which != only) continue;
+                setenv("LDX_ATTN_PIPE", which == 0 ? "0" : (which == 1 ? "1" : "2"), 1);
+                void* o = which == 0 ? dout0 : (which == 1 ? dout1 : dout2);
                 for (int i = 0; i < 3; ++i) run(p, scale, dq, o, st);
                 CK(hipEventRecord(e0, st));
                 for (int i = 0; i < reps; ++i) run(p, scale, dq, o, st);
                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("timing N%d round %d %-10s %.1f us / launch  %.0f TFLOP/s (%.3f of 2.5 PF)\n", p.N, round, which ? "pipelined" : "attn32*", ms * 1e3 / reps, flop / (ms / reps * 1e-3) * 1e-12, flop / (ms / reps * 1e-3) / 2.5e15);
+                printf("timing N%d round %d %-10s %.1f us / launch  %.0f TFLOP/s (%.3f of 2.5 PF)\n", p.N, round, which == 0 ? "attn32*" : (which == 1 ? "pipe-4w" : "pipe-8w"), ms * 1e3 / reps, flop / (ms / reps * 1e-3) * 1e-12, flop / (ms / reps * 1e-3) / 2.5e15);
             }
         std::vector<uint16_t> a((size_t)p.B * p.N * C), b(a.size());
-        CK(hipMemcpy(a.data(), dout0, a.size() * 2, hipMemcpyDeviceToHost)); CK(hipMemcpy(b.data(), dout1, b.size() * 2, hipMemcpyDeviceToHost));
-        double num = 0, den = 0; for (size_t i = 0; i < a.size(); ++i) { const double x = bf2f(a[i]), y = bf2f(b[i]); num += (x - y) * (x - y); den += x * x; }
-        printf("big problem: pipelined vs attn32* rel-L2 %.3e\n", std::sqrt(num / den));
+        CK(hipMemcpy(a.data(), dout0, a.size() * 2, hipMemcpyDeviceToHost));
+        for (void* d : {dout1, dout2}) {
+            CK(hipMemcpy(b.data(), d, b.size() * 2, hipMemcpyDeviceToHost));
+            double num = 0, den = 0; for (size_t i = 0; i < a.size(); ++i) { const double x = bf2f(a[i]), y = bf2f(b[i]); num += (x - y) * (x - y); den += x * x; }
+            printf("big problem: %s vs attn32* rel-L2 %.3e\n", d == dout1 ? "pipe-4w" : "pipe-8w", std::sqrt(num / den));
+        }
     }
     return 0;
 }
