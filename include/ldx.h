@@ -137,6 +137,12 @@ int ldx_finalize(ldx_engine* e);
  *   ctx     [B2][M][context_dim] fp32 (c["c_crossattn"]), out_nchw like x_nchw.  */
 int ldx_unet_denoise(ldx_engine* e, const float* x_nchw, const float* sigma, const float* ctx,
                      int B2, int h, int w, int M, float* out_nchw, void* stream);
+/* The same with the concat conditioning of inpainting UNets (BaseModel.apply_model, ModelBase.py:100-101:
+ * xc = torch.cat((x / sqrt(sigma^2 + 1), c_concat), dim=1)): x_nchw [B2][in_channels - cc_channels][h][w] is the latent (scaled, and the x of
+ * denoised = x - eps * sigma), c_concat [B2][cc_channels][h][w] fp32 is appended UNSCALED; the engine's in_channels (9 for SD1.5 inpainting) counts
+ * both.  LDX_EINVAL unless in_channels - cc_channels == out_channels. */
+int ldx_unet_denoise_concat(ldx_engine* e, const float* x_nchw, const float* sigma, const float* ctx, const float* c_concat, int cc_channels,
+                            int B2, int h, int w, int M, float* out_nchw, void* stream);
 /* One CFG evaluation as calc_cond_batch builds it (cond/cond.py:186-226: input_x = cat([x] * 2), timestep = cat([sigma] * 2),
  * c_crossattn = cat([uncond, cond])): x_nchw [B][C][h][w] is read by BOTH halves of the [uncond x B ; cond x B] batch, sigma is
  * one host scalar shared by every sample, ctx [2B][M][context_dim], out_nchw [2B][C][h][w].  Same arithmetic as
@@ -160,6 +166,10 @@ int ldx_profile(ldx_engine* e, int enable, int reset);
 int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap);
 /* Capture the planned forward into a hipGraph for replay (0 = eager launches). */
 int ldx_set_graph_mode(ldx_engine* e, int enable);
+/* UNet engine: how many times a forward was captured into a hipGraph and how many times a captured graph was replayed since the engine was
+ * created (a captured graph is tied to the pointers of the call that recorded it: a caller that alternates buffers re-captures instead of
+ * replaying — sampling.CFGDenoiser stages such inputs through one persistent buffer per shape). */
+int ldx_graph_stats(ldx_engine* e, int64_t* captures, int64_t* replays);
 
 /* ---- VAE decode and CLIP text encode (same ldx_engine handle type; load/finalize/destroy as above) ---------- */
 /* Keys for ldx_load_tensor: the reference's first_stage_model state dict ("decoder.*", "post_quant_conv.*"). */

@@ -94,7 +94,8 @@ template <int LO, int... I> constexpr auto ap_range_impl(std::integer_sequence<i
 template <int LO, int HI> constexpr auto ap_range() { return ap_range_impl<LO>(std::make_integer_sequence<int, HI - LO>{}); }
 template <int N> using ap_ic = std::integral_constant<int, N>;
 
-template <typename T>
+// ABL: timing ablations (wrong results; LDX_ATTN_PIPE_ABL, profiles/ubench): 1 no s_barrier, 2 no maximum, 8 no staging, 16 no fragment re-reads, 32 no exponentials
+template <typename T, int ABL>
 __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const float thr) {
     constexpr int KROWB = 144, VROWB = 192, KVB = 64, D = 40, DCH = 5;
     constexpr int KBYTES = KVB * KROWB, VBYTES = KVB * VROWB;
@@ -234,11 +235,12 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     auto piece = [&](auto K, const f32x16 (&s)[2][2], ap_i32x4 (&pf)[2][4]) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value, qt = k >> 4, st = (k >> 2) & 3, w = k & 3;
         const float a = s[st >> 1][qt][8 * (st & 1) + 2 * w], bb = s[st >> 1][qt][8 * (st & 1) + 2 * w + 1];
-        if constexpr (k < 2) ap_piece0(a, bb, ex[k], ey[k]);
+        if constexpr (ABL & 32) { int r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb)); pf[qt][st][w] = r; }
+        else if constexpr (k < 2) ap_piece0(a, bb, ex[k], ey[k]);
         else { constexpr int j = k - 2; pf[j >> 4][(j >> 2) & 3][j & 3] = ap_piece<T>(a, bb, ex[k % 3], ey[k % 3], ex[j % 3], ey[j % 3]); }
     };
     // maximum of S'(t+1): block m in [0, 8): (qt, kt, half) = (m >> 2, (m >> 1) & 1, m & 1), eight registers each
-    float mx[8];
+    float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto maxblk = [&](auto M, const f32x16 (&s)[2][2]) __attribute__((always_inline)) {
         constexpr int m = decltype(M)::value, qt = m >> 2, kt = (m >> 1) & 1, r0 = 8 * (m & 1);
         const f32x16& v = s[kt][qt];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         ap_for(ap_range<0, 12>(), [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             qk1(I, sn);
-            if constexpr (i < 3) gload1(i, t + 3, t + 1);
+            if constexpr (i < 3 && !(ABL & 8)) gload1(i, t + 3, t + 1);
             // pieces 0 .. 17: two in even gaps, one in odd gaps
             constexpr int k0 = 3 * (i >> 1) + 2 * (i & 1);
             piece(ap_ic<k0>{}, sc, pc);
@@ -307,23 +309,23 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
             __builtin_amdgcn_sched_barrier(0);
         });
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         float bm0 = 0.f, bm1 = 0.f;
         ap_for(ap_range<12, 28>(), [&](auto I) __attribute__((always_inline)) {
             constexpr int i = decltype(I)::value;
             pv1(ap_ic<i - 12>{}, pp, vfc);           // P(t-1) x V(t-1)
-            if constexpr (i < 20) vread1(vfn, (i - 12) >> 1, (i - 12) & 1, par);                             // V(t), staged in slot t - 1, into the other fragment set
-            if constexpr (i >= 18 && i < 24) kread1((i - 18) >> 1, (i - 18) & 1, par);                       // K(t+2), staged in slot t - 1 (this slot's QK^T MFMAs are issued)
-            if constexpr (i == 19 || i == 21 || i == 23) lstore1((i - 19) >> 1, par ^ 1);                    // K(t+3), V(t+1)
+            if constexpr (i < 20 && !(ABL & 16)) vread1(vfn, (i - 12) >> 1, (i - 12) & 1, par);                             // V(t), staged in slot t - 1, into the other fragment set
+            if constexpr (i >= 18 && i < 24 && !(ABL & 16)) kread1((i - 18) >> 1, (i - 18) & 1, par);                       // K(t+2), staged in slot t - 1 (this slot's QK^T MFMAs are issued)
+            if constexpr ((i == 19 || i == 21 || i == 23) && !(ABL & 8)) lstore1((i - 19) >> 1, par ^ 1);                    // K(t+3), V(t+1)
             // pieces 18 .. 23 in gaps 12-15 (2, 1, 2, 1); 24 .. 27 in gaps 16, 18, 20, 22; 28 .. 31 in gaps 24-27
             if constexpr (i < 16) { constexpr int k0 = 18 + 3 * ((i - 12) >> 1) + 2 * (i & 1); piece(ap_ic<k0>{}, sc, pc); if constexpr (!(i & 1)) piece(ap_ic<k0 + 1>{}, sc, pc); }
             else if constexpr (i < 24) { if constexpr (!(i & 1)) piece(ap_ic<24 + ((i - 16) >> 1)>{}, sc, pc); }
             else piece(ap_ic<28 + (i - 24)>{}, sc, pc);
-            if constexpr (i >= 16 && i < 24) maxblk(ap_ic<i - 16>{}, sn);                          // S'(t+1): its last MFMA issued in gap 11
-            if constexpr (i == 24) bm0 = bmax(0);
-            if constexpr (i == 25) bm1 = bmax(1);
+            if constexpr (i >= 16 && i < 24 && !(ABL & 2)) maxblk(ap_ic<i - 16>{}, sn);                          // S'(t+1): its last MFMA issued in gap 11
+            if constexpr (i == 24 && !(ABL & 2)) bm0 = bmax(0);
+            if constexpr (i == 25 && !(ABL & 2)) bm1 = bmax(1);
             __builtin_amdgcn_sched_barrier(0);
         });
         pc[1][3][2] = ap_pack<T>(ex[30 % 3], ey[30 % 3]);      // packs of pieces 30, 31
@@ -383,16 +385,33 @@ bool attn_pipe_ok(const AttnArgs& a) {
            a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0;
 }
 
-template <typename T>
+template <typename T, int ABL = 0>
 static void launch_attn40p(const AttnArgs& a, hipStream_t s, float thr) {
     const size_t lds = 2 * 64 * (144 + 192);
     dim3 grid((a.Nq / 256) * a.H * a.B);
-    hipLaunchKernelGGL((attn40p_kernel<T>), grid, dim3(256), lds, s, a, thr);
+    hipLaunchKernelGGL((attn40p_kernel<T, ABL>), grid, dim3(256), lds, s, a, thr);
 }
 
 // thr_override: NaN = the type's default (tests force the rare path with small values)
 void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override) {
     const bool ov = thr_override == thr_override;
+#ifdef LDX_ATTN_ABLATE
+    if (const char* e = getenv("LDX_ATTN_PIPE_ABL")) {
+        const float thr = ApT<__bf16>::thr;
+        switch (atoi(e)) {
+            case 1: launch_attn40p<__bf16, 1>(a, s, thr); return;
+            case 2: launch_attn40p<__bf16, 2>(a, s, thr); return;
+            case 8: launch_attn40p<__bf16, 8>(a, s, thr); return;
+            case 16: launch_attn40p<__bf16, 16>(a, s, thr); return;
+            case 32: launch_attn40p<__bf16, 32>(a, s, thr); return;
+            case 9: launch_attn40p<__bf16, 9>(a, s, thr); return;
+            case 25: launch_attn40p<__bf16, 25>(a, s, thr); return;
+            case 27: launch_attn40p<__bf16, 27>(a, s, thr); return;
+            case 59: launch_attn40p<__bf16, 59>(a, s, thr); return;
+            default: break;
+        }
+    }
+#endif
     if (dt == DT_BF16) launch_attn40p<__bf16>(a, s, ov ? thr_override : ApT<__bf16>::thr);
     else launch_attn40p<_Float16>(a, s, ov ? fminf(thr_override, ApT<_Float16>::thr) : ApT<_Float16>::thr);
 }

@@ -227,6 +227,15 @@ int ldx_unet_denoise(ldx_engine* e, const float* x, const float* sigma, const fl
     return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_unet_denoise_concat(ldx_engine* e, const float* x, const float* sigma, const float* ctx, const float* c_concat, int cc_channels, int B2, int h, int w, int M,
+                            float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise_concat: not a UNet engine"); return LDX_ESTATE; }
+    if (!c_concat) { set_error("ldx_unet_denoise_concat: c_concat is null (use ldx_unet_denoise)"); return LDX_EINVAL; }
+    return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream, 0, c_concat, cc_channels);
+    GUARD_END
+}
 int ldx_unet_denoise_cfg(ldx_engine* e, const float* x, float sigma, const float* ctx, int B, int h, int w, int M, float* out, void* stream) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
@@ -265,6 +274,11 @@ int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap) {
 int ldx_set_graph_mode(ldx_engine* e, int enable) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     e->impl->graph_mode = enable != 0;
+    return LDX_OK;
+}
+int ldx_graph_stats(ldx_engine* e, int64_t* captures, int64_t* replays) {
+    if (!e || !captures || !replays) { set_error("ldx_graph_stats: bad argument"); return LDX_EINVAL; }
+    *captures = e->impl->n_graph_captures; *replays = e->impl->n_graph_replays;
     return LDX_OK;
 }
 

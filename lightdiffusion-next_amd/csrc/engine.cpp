@@ -940,7 +940,7 @@ void Engine::plan_stash() {
     s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.ops = std::move(ops); s.flops = flops; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
-    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB;
+    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB; s.g_cc = g_cc; s.g_ccn = g_ccn;
     s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
     s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
     s.fb_B = fb_B; s.fb_L = fb_L; s.fb_Lt = fb_Lt; s.fb_C = fb_C; s.fb_a_end = fb_a_end; s.fb_b_end = fb_b_end;
@@ -964,7 +964,7 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc) {
         ops = std::move(s.ops); flops = s.flops; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
-        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB;
+        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB; g_cc = s.g_cc; g_ccn = s.g_ccn;
         fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
         fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
         fb_B = s.fb_B; fb_L = s.fb_L; fb_Lt = s.fb_Lt; fb_C = s.fb_C; fb_a_end = s.fb_a_end; fb_b_end = s.fb_b_end;
@@ -993,6 +993,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
                 p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
                 p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
                 p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s; p.xB = b_xB;
+                p.cc = b_cc; p.Cx = cfg.in_channels - b_ccn;
                 launch_prep(p, dt, ls);
             } break;
             case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
@@ -1090,7 +1091,12 @@ int Engine::run_cfg(const float* x, float sigma, const float* ctx, int B, int h,
     return run(x, d_sigma_cfg, ctx, 2 * B, h, w, Mc, out, true, st, B);
 }
 
-int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB) {
+int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB,
+                const float* c_concat, int cc_channels) {
+    if (c_concat && (cc_channels <= 0 || cc_channels >= cfg.in_channels || (denoise && cfg.in_channels - cc_channels != cfg.out_channels))) {
+        set_error("ldx_unet_denoise_concat: c_concat channels must leave the latent's channels (in_channels - cc_channels == out_channels)"); return LDX_EINVAL;
+    }
+    if (!c_concat) cc_channels = 0;
     if (xB < 0 || (xB > 0 && B2 % xB != 0)) { set_error("ldx_unet_*: the batch of x must divide the evaluation batch"); return LDX_EINVAL; }
     if (!finalized) { set_error("ldx_unet_*: engine not finalized"); return LDX_ESTATE; }
     if (!x || !sigma_or_t || !ctx || !out || B2 <= 0 || h <= 0 || w <= 0 || Mc <= 0) { set_error("ldx_unet_*: bad argument"); return LDX_EINVAL; }
@@ -1103,18 +1109,19 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
             if (rc) return rc;
         }
     }
-    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB);
+    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB && g_cc == c_concat && g_ccn == cc_channels);
     // a captured graph has its pointers baked in: once a call arrives with other bindings (in ANY mode — the eager path below re-records
     // g_*), that graph must never be replayed against the new g_* (round 3: a stale graph was replayed after an eager call had moved g_*)
     if (!same) graph_valid = false;
     if (graph_mode && graph_valid && same) {
         HIP_OK(hipGraphLaunch(graph_exec, st));
+        ++n_graph_replays;
         return LDX_OK;
     }
     // capture only once the same (plan, pointers) have been run eagerly before: the first eager pass
     // also performs the one-time hipFuncSetAttribute calls, which are illegal during capture.
     const bool use_graph = graph_mode && warm && same;
-    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; warm = true;
+    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; g_cc = c_concat; g_ccn = cc_channels; warm = true;
     hipStream_t ls = st;
     if (use_graph) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -1123,7 +1130,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         ls = cap_stream;
     }
-    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB;
+    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB; b_cc = c_concat; b_ccn = cc_channels;
     prof_graph = use_graph;
     { int rc = exec_ops(ls); if (rc) return rc; }
     if (use_graph) {
@@ -1132,6 +1139,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipGraphInstantiate(&graph_exec, g, nullptr, nullptr, 0));
         (void)hipGraphDestroy(g);
         graph_valid = true;
+        ++n_graph_captures;
         HIP_OK(hipGraphLaunch(graph_exec, st));
     }
     hipError_t e = hipGetLastError();

@@ -114,13 +114,16 @@ public:
     int load_tensor(const char* key, const void* data, int dtype, const int64_t* shape, int ndim);
     int set_tables(const float* ls, int n, const float* temb, int dim);
     int finalize();
-    int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB = 0);
+    // c_concat [B2][cc_channels][h][w] (fp32, may be null): appended unscaled behind the scaled x, which then carries in_channels - cc_channels channels
+    int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB = 0,
+            const float* c_concat = nullptr, int cc_channels = 0);
     int clip_pooled(const float* last, const int* ids, int B, int T, int eos_id, float* out, hipStream_t st);
     // one CFG evaluation: x [B] is read by both halves of the [uncond; cond] batch (cond.py:186-226), sigma is one host scalar for every sample
     int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st);
     float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;
     int plan(int B2, int h, int w, int Mc);
     int64_t n_launches() const;
+    int64_t n_graph_captures = 0, n_graph_replays = 0;      // ldx_graph_stats (tests: the sampler loops must replay, not re-capture)
     // per-kernel-class HIP-event profile of subsequent forwards (bench.py roofline leg)
     bool profiling = false, prof_detail = false;   // detail: key the report by op shape as well
     std::map<std::string, ProfEntry> prof;
@@ -161,6 +164,7 @@ private:
     bool op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw);          // post-pass over ops: GroupNorms whose input was just written by a fusable GEMM / conv get their statistics from its epilogue
     // per-call bindings read by exec_ops
     const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false; int b_xB = 0, g_xB = 0;
+    const float* b_cc = nullptr; const float* g_cc = nullptr; int b_ccn = 0, g_ccn = 0;
     const int* b_ids = nullptr; float* b_out2 = nullptr;
     // VAE
     std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
@@ -227,7 +231,7 @@ private:
         int B2 = 0, h = 0, w = 0, M = 0; std::vector<Op> ops; double flops = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
-        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0;
+        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0; const float* g_cc = nullptr; int g_ccn = 0;
         // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
         float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
         void *fb_s0 = nullptr, *fb_s1 = nullptr, *fb_x = nullptr; float *fb_first = nullptr, *fb_res = nullptr, *fb_part = nullptr;

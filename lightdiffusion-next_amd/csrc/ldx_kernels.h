@@ -204,6 +204,9 @@ struct PrepArgs {
     int scale_input;                 // 1: divide by sqrt(sigma^2+1) ; 0: raw (ldx_unet_forward)
     const float* t_in;               // if non-null: timestep indices given directly (no sigma lookup)
     int xB;                          // batch of x (0 = B): sample b reads x[b % xB] — the [uncond; cond] halves of a CFG evaluation share one latent
+    // c_concat (ModelBase.py:100-101: xc = cat((x / sqrt(sigma^2 + 1), c_concat), 1); inpainting UNets, in_channels = 9): x carries Cx channels,
+    // channels Cx .. C - 1 come UNSCALED from cc [B][C - Cx][H][W].  cc == null: x carries all C channels (Cx is ignored)
+    const float* cc; int Cx;
 };
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s);
 // finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)

@@ -25,11 +25,12 @@ __global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p) {
         float scale = 1.f;
         if (p.scale_input) { const float sg = p.sigma[b]; scale = 1.0f / sqrtf(sg * sg + 1.0f); }
         const int bx = p.xB > 0 ? b % p.xB : b;
+        const int Cx = p.cc ? p.Cx : p.C;
         float f[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = ch * 8 + e;
-            f[e] = (c < p.C) ? p.x[((long)bx * p.C + c) * HW + pix] * scale : 0.f;
+            f[e] = c < Cx ? p.x[((long)bx * Cx + c) * HW + pix] * scale : (c < p.C ? p.cc[((long)b * (p.C - Cx) + (c - Cx)) * HW + pix] : 0.f);
         }
         *(uint4*)((T*)p.xc + ((long)b * HW + pix) * p.Cpad + ch * 8) = pack8<T>(f);
     }

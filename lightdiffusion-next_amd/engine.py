@@ -88,6 +88,12 @@ class UNetEngine:
     def set_graph_mode(self, on: bool):
         lib.check(self._lib.ldx_set_graph_mode(self._h, int(on)), "ldx_set_graph_mode")
 
+    def graph_stats(self):
+        """(captures, replays) of the engine's hipGraph path since it was created."""
+        c, r = C.c_int64(0), C.c_int64(0)
+        lib.check(self._lib.ldx_graph_stats(self._h, C.byref(c), C.byref(r)), "ldx_graph_stats")
+        return int(c.value), int(r.value)
+
     def _run(self, fn, x, s, ctx, out):
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
         b2, ch, h, w = x.shape
@@ -102,9 +108,24 @@ class UNetEngine:
                      lib.current_stream_ptr()), fn.__name__)
         return out
 
-    def denoise(self, x, sigma, ctx, out=None):
-        """BaseModel.apply_model (ModelBase.py:72-133): x fp32 [B2,4,h,w], sigma [B2] (values), ctx [B2,M,768]."""
-        return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out)
+    def denoise(self, x, sigma, ctx, out=None, c_concat=None):
+        """BaseModel.apply_model (ModelBase.py:72-133): x fp32 [B2,4,h,w], sigma [B2] (values), ctx [B2,M,768].
+        c_concat [B2,in_channels-4,h,w] (inpainting UNets, ModelBase.py:100-101): appended unscaled behind the scaled x inside the engine's prep kernel."""
+        if c_concat is None:
+            return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out)
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
+        b2, ch, h, w = x.shape
+        cc = c_concat.to(device=x.device, dtype=torch.float32).contiguous()
+        assert cc.dim() == 4 and cc.shape[0] == b2 and cc.shape[2:] == x.shape[2:] and ch + cc.shape[1] == self.cfg.in_channels, "c_concat must be [B2, in_channels - C(x), h, w]"
+        x = x.contiguous()
+        s = sigma.to(device=x.device, dtype=torch.float32).contiguous()
+        ctx = ctx.to(device=x.device, dtype=torch.float32).contiguous()
+        assert s.numel() == b2 and ctx.dim() == 3 and ctx.shape[0] == b2 and ctx.shape[2] == self.cfg.context_dim
+        if out is None:
+            out = torch.empty((b2, self.cfg.out_channels, h, w), device=x.device, dtype=torch.float32)
+        lib.check(self._lib.ldx_unet_denoise_concat(self._h, lib.ptr(x), lib.ptr(s), lib.ptr(ctx), lib.ptr(cc), cc.shape[1], b2, h, w, ctx.shape[1],
+                                                    lib.ptr(out), lib.current_stream_ptr()), "ldx_unet_denoise_concat")
+        return out
 
     def denoise_cfg(self, x, sigma: float, ctx, out=None):
         """One CFG evaluation (calc_cond_batch, cond.py:186-226): x fp32 [B,4,h,w] is read by both halves of the [uncond x B; cond x B]

@@ -32,12 +32,14 @@ class LdxUNetPatch:
         ctx = c.get("c_crossattn")
         if ctx is None:
             raise ValueError("LdxUNetPatch: c['c_crossattn'] is required (SD1.5 cross-attention context)")
-        for k in ("c_concat", "control", "y"):
+        for k in ("control", "y"):
             if c.get(k) is not None:
                 raise NotImplementedError(f"LdxUNetPatch: conditioning '{k}' is outside the SD1.5 hot path")
         src_device = x.device
         dev = self.engine.device
-        out = self.engine.denoise(x.to(dev, torch.float32), sigma.to(dev, torch.float32), ctx.to(dev, torch.float32))
+        cc = c.get("c_concat")            # inpainting UNets (in_channels = 9): ModelBase.py:100-101, concatenated inside the engine's prep kernel
+        out = self.engine.denoise(x.to(dev, torch.float32), sigma.to(dev, torch.float32), ctx.to(dev, torch.float32),
+                                  c_concat=None if cc is None else cc.to(dev, torch.float32))
         return out if src_device == dev else out.to(src_device)
 
     def to(self, device):

@@ -70,11 +70,13 @@ _SIGS = {
     "ldx_finalize": (_i, [_vp]),
     "ldx_unet_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_denoise_cfg": (_i, [_vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_denoise_concat": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_plan_info": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ldx_profile": (_i, [_vp, _i, _i]),
     "ldx_profile_report": (_i, [_vp, C.c_char_p, _i64]),
     "ldx_set_graph_mode": (_i, [_vp, _i]),
+    "ldx_graph_stats": (_i, [_vp, C.POINTER(_i64), C.POINTER(_i64)]),
     "ldx_vae_create": (_i, [C.POINTER(ldx_vae_config), _i, C.POINTER(_vp)]),
     "ldx_vae_decode": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp]),
     "ldx_clip_create": (_i, [C.POINTER(ldx_clip_config), _i, C.POINTER(_vp)]),

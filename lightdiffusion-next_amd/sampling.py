@@ -190,6 +190,7 @@ class CFGDenoiser:
         self.batch = batch
         self.simple = (not self.skip_uncond) and sides == [1, 0]
         self._bufs = {}
+        self._xsrc = {}         # per input shape: [data_ptr of the caller's x, persistent staging tensor or None]
 
     def _buffers(self, shape):
         key = tuple(shape)
@@ -217,7 +218,17 @@ class CFGDenoiser:
         xin, sig, out = self._buffers(x.shape)
         b = self.batch
         if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
-            # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg): no torch copy / fill kernels in the loop
+            # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg): no torch copy / fill kernels in the loop.  The engine's captured
+            # graph is tied to the pointer of x: a sampler that updates x in place (euler, dpmpp_2m) keeps handing over the same tensor and is
+            # passed through; one that alternates tensors (dpmpp_sde's x / x2, the multi-scale steps' fresh _bilinear outputs) would invalidate
+            # the graph on every call, so from the first change of pointer on this shape goes through ONE persistent staging tensor (one small
+            # device copy per evaluation instead of an eager ~350-launch forward or a re-capture).
+            src = self._xsrc.setdefault(tuple(x.shape), [x.data_ptr(), None])
+            if src[1] is None and src[0] != x.data_ptr():
+                src[1] = torch.empty_like(x)
+            if src[1] is not None:
+                src[1].copy_(x)
+                x = src[1]
             self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out)
             return out[:b], out[b:]
         for i in range(self.n_entries):                     # the general case (cfg 1 / several entries per side): host-side batch assembly

@@ -189,11 +189,14 @@ def unet_forward(sd, cfg, x, timesteps, context):
     return F.conv2d(h, w("out.2.weight"), w("out.2.bias"), padding=1)
 
 
-def apply_model(sd, cfg, x, sigma, context):
+def apply_model(sd, cfg, x, sigma, context, c_concat=None):
     """BaseModel.apply_model (src/Model/ModelBase.py:72-133) with EPS (sampling.py:26-56):
-    xc = x / sqrt(sigma^2 + 1); t = timestep(sigma).float(); denoised = x - out * sigma."""
+    xc = x / sqrt(sigma^2 + 1); t = timestep(sigma).float(); denoised = x - out * sigma.
+    c_concat (ModelBase.py:100-101, inpainting UNets): appended UNSCALED behind the scaled x; the denoised latent still is x - out * sigma."""
     s = sigma.view(sigma.shape[:1] + (1,) * (x.ndim - 1))
     xc = x / (s ** 2 + 1.0) ** 0.5
+    if c_concat is not None:
+        xc = torch.cat((xc, c_concat), dim=1)
     t = timestep(sigma).float()
     out = unet_forward(sd, cfg, xc.float(), t, context.float()).float()
     return x - out * s

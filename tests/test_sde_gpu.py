@@ -42,3 +42,29 @@ def test_dpmpp_sde_cfgpp(ldx, g, unet, dt, tol):
     r2 = _rel(out, g["sde_img2img"])
     print(f"[{dt}] dpmpp_sde_cfgpp txt2img {r1:.3e} img2img {r2:.3e}")
     assert r1 <= tol and r2 <= tol
+
+
+def test_graph_is_replayed_across_sde_and_multiscale_steps(ldx, g, unet):
+    """Round-3 advisor finding: the engine's captured graph is tied to the pointer of x, and dpmpp_sde_cfgpp alternates x / x2 while the multi-scale
+    steps hand over fresh _bilinear tensors, so graph mode silently fell back to eager launches or re-captured on most evaluations.  CFGDenoiser now
+    stages such inputs through one persistent tensor per shape: over a 20-step run (39 evaluations, two resolutions) the graph must be captured a
+    handful of times (once per shape, plus the re-capture when a shape's input moves to the staging tensor) and replayed for nearly everything
+    else — and the latents must equal the eager run's bit for bit."""
+    e = unet["f16"]
+    ks = ldx.sampling.KSampler(e)
+    P, N = torch.from_numpy(g["P"]), torch.from_numpy(g["N"])
+    kw = dict(seed=11, steps=20, cfg=7.0, denoise=1.0, positive=P, negative=N, latent_image=torch.zeros(1, 4, 16, 16),
+              sampler_name="dpmpp_sde_cfgpp", scheduler="karras")
+    eager = ks.sample(**kw).clone()
+    c0, r0 = e.graph_stats()
+    e.set_graph_mode(True)
+    try:
+        trace = []
+        out = ks.sample(trace=trace, **kw)
+    finally:
+        e.set_graph_mode(False)
+    c1, r1 = e.graph_stats()
+    captures, replays, evals = c1 - c0, r1 - r0, len(trace)
+    print(f"dpmpp_sde_cfgpp graph mode: {evals} evaluations, {captures} captures, {replays} replays")
+    assert torch.equal(out, eager)
+    assert evals == 39 and captures <= 4 and replays >= evals - 10, (evals, captures, replays)
