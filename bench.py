@@ -213,6 +213,34 @@ def _roof(flops, ms, peak, unit_note):
     return {"bound": "mfma", "achieved": round(tf, 1), "peak": peak, "unit": "TFLOP/s", "frac": round(tf / peak, 4), "traffic": None, "of": unit_note}
 
 
+def sd15_512_line(ldx, eng, cfg, steps):
+    """BASELINE config 1's shape on the GPU engine (SD1.5 512 x 512, latent 64^2, CFG batch 2; the reference runs that config on its CPU path): same loop as the
+    headline at a quarter of the pixels, where the step is a flat profile of 10-20 us kernels."""
+    lat = 64
+    ms_ = ldx.sampling.ModelSamplingDiscrete()
+    sig = ldx.sampling.calculate_sigmas(ms_, "normal", steps + 2)
+    g = torch.Generator().manual_seed(13)
+    pos, neg = torch.randn([1, 77, cfg.context_dim], generator=g), torch.randn([1, 77, cfg.context_dim], generator=g)
+    x = (torch.randn([1, 4, lat, lat], generator=g) * torch.sqrt(1.0 + sig[0] ** 2.0)).cuda()
+    model = ldx.sampling.CFGDenoiser(eng, pos, neg, 7.0, 1, lat, lat)
+
+    def run(i0, n):
+        for i in range(i0, i0 + n):
+            du, dc = model(x, sig[i])
+            ldx.sampling._step(0, x, du, dc, 7.0, sig[i], sig[i + 1] - sig[i])
+    run(0, 2); torch.cuda.synchronize()
+    x0 = x.clone(); ts = []
+    for _ in range(3):
+        x.copy_(x0); torch.cuda.synchronize(); t0 = time.perf_counter()
+        run(2, steps); torch.cuda.synchronize(); ts.append((time.perf_counter() - t0) / steps)
+    ms = 1e3 * statistics.median(ts)
+    info = eng.plan_info()
+    assert torch.isfinite(x).all()
+    return {"workload": f"SD1.5 512^2 bs=1 (latent 64^2, CFG batch 2), sample_euler/normal, {steps} steps x 3 regions (median)",
+            "ms_per_step": round(ms, 3), "it_per_s": round(1e3 / ms, 2), "step_tflop": round(info["flops"] / 1e12, 3), "launches_per_step": info["launches"],
+            "roofline": _roof(info["flops"], ms, PEAK_BF16_TFLOPS, "whole step, dense bf16 MFMA peak")}
+
+
 def config3_shard_line(ldx, eng, cfg, lat, steps):
     """SURVEY config 3's PER-GPU shard on one GPU: 8 latents, CFG batch 16, same loop as the headline (pipeline shape bs = 64 over 8 GPUs)."""
     pb = 8
@@ -440,6 +468,26 @@ def main(argv=None):
     assert gathered.shape[0] == gb, (gathered.shape, gb)
     assert torch.isfinite(gathered).all(), "non-finite latents"
 
+    # The same collective once more through the DIRECT RCCL path (ctypes on librccl.so: ncclCommInitRank + ncclAllGather on this stream; the unique id
+    # travels through the process group's store, not a data-path collective).  Outside the timed regions and guarded: the first multi-GPU run of this
+    # code must not lose its headline to an untested call; the line reports whether it ran, its time, and that it returned the same bytes.
+    rccl_direct = None
+    if world > 1 and not stub:
+        try:
+            def _xchg(r, make_id):
+                box = [make_id() if r == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            comm = ldx.parallel.RcclComm(rank, world, id_exchange=_xchg)
+            comm.all_gather_latents(x, gb); sync()                                   # warm
+            fence(); td0 = time.perf_counter()
+            direct = comm.all_gather_latents(x, gb); sync()
+            td1 = time.perf_counter()
+            rccl_direct = {"ok": True, "ms": round(1e3 * (td1 - td0), 3), "equal_to_torch_distributed": bool(torch.equal(direct, gathered))}
+            comm.close()
+        except Exception as e:      # noqa: BLE001 — reported in the line
+            rccl_direct = {"ok": False, "error": repr(e)[:300]}
+
     # MAX over ranks per region; per-rank medians for the report
     per_rank_ms = [1000.0 * statistics.median(regions) / args.steps]
     if dist:
@@ -525,7 +573,8 @@ def main(argv=None):
         secondary = secondary_lines(ldx, eng, cfg, lat, args.steps)
         if lat == 128 and not args.no_configs:
             # SURVEY §8(d) configs 3, 4, 5 on the driver's clock (each guarded: a failure is reported in the line, the headline stays valid)
-            for key, fn in (("config3_shard", lambda: config3_shard_line(ldx, eng, cfg, lat, 10)),
+            for key, fn in (("sd15_512", lambda: sd15_512_line(ldx, eng, cfg, 40)),
+                            ("config3_shard", lambda: config3_shard_line(ldx, eng, cfg, lat, 10)),
                             ("hiresfix_2048", lambda: hiresfix_line(ldx, eng, cfg)),
                             ("flux", lambda: flux_lines(ldx))):
                 t0 = time.perf_counter()
@@ -572,7 +621,7 @@ def main(argv=None):
                        "region_ms_per_step": [round(1000.0 * r / args.steps, 3) for r in regions_max],
                        "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
                        "allgather_ms": round(1000.0 * statistics.median(gathers_max), 3),
-                       "allgather_bytes": int(gathered.numel() * 4),
+                       "allgather_bytes": int(gathered.numel() * 4), "rccl_direct": rccl_direct,
                        "backend": (dist.get_backend() if dist else None), "rccl_ranks": (dist.get_world_size() if dist else 1),
                        "latents_sha256_16": hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,

@@ -46,11 +46,27 @@ static float* op_workspace(size_t floats) {
     }
     return buf[dev];
 }
+// tile counters of the in-kernel split-K reduction for the single-op entry points: per device, zeroed once, left at zero by every launch (same
+// one-stream-per-device rule as the workspace)
+static unsigned* op_sk_counters() {
+    static std::mutex mu;
+    static unsigned* buf[64] = {nullptr};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev &= 63;
+    std::lock_guard<std::mutex> lock(mu);
+    if (!buf[dev]) {
+        if (hipMalloc((void**)&buf[dev], sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { buf[dev] = nullptr; return nullptr; }
+        if (hipMemset(buf[dev], 0, sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { (void)hipFree(buf[dev]); buf[dev] = nullptr; return nullptr; }
+    }
+    return buf[dev];
+}
 static int attach_splitk(GemmArgs& g) {
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, g.geglu != 0);
     if (g.splitk > 1) {
-        g.ws = op_workspace((size_t)g.splitk * g.M * g.N);
+        g.ws = op_workspace(gemm_sk_ws_floats(g.M, g.N, g.splitk));
         if (!g.ws) { set_error("split-K workspace allocation failed"); return LDX_EHIP; }
+        g.sk_count = op_sk_counters();
     }
     return LDX_OK;
 }
@@ -367,8 +383,9 @@ int ldx_op_gemm_mx(const void* A8, int lda, const void* SA, int sa_ld, const voi
     g.C8 = C8; g.ldc8 = ldc8; g.c8_col = 0; g.SC = (uint32_t*)SC; g.sc_ld = sc_ld;
     g.splitk = C8 ? 1 : gemm_choose_splitk(M, N, K / 2, false);
     if (g.splitk > 1) {
-        g.ws = op_workspace((size_t)g.splitk * M * N);
+        g.ws = op_workspace(gemm_sk_ws_floats(M, N, g.splitk));
         if (!g.ws) { set_error("split-K workspace allocation failed"); return LDX_EHIP; }
+        g.sk_count = op_sk_counters();
     }
     launch_gemm(g, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_gemm_mx");

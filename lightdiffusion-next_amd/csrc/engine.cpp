@@ -517,6 +517,16 @@ void Engine::a_free(size_t off) {
     }
 }
 
+// Tile counters of the in-kernel split-K reduction (GemmArgs::sk_count): the engine's launches run in stream order and each leaves them at zero.
+unsigned* Engine::sk_counters() {
+    if (!d_sk_count) {
+        if (hipMalloc((void**)&d_sk_count, sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { d_sk_count = nullptr; return nullptr; }
+        if (hipMemset(d_sk_count, 0, sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { (void)hipFree(d_sk_count); d_sk_count = nullptr; return nullptr; }
+        dev_allocs.push_back(d_sk_count);
+    }
+    return d_sk_count;
+}
+
 // ---- op emitters ---------------------------------------------------------------------------------
 void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bool geglu, const float* rowvec, int rv_ld, int rpb) {
     Op o{}; o.kind = OP_GEMM; o.name = name;
@@ -527,7 +537,7 @@ void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bo
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = ptr(C); g.ldc = C.ld; g.Cf = nullptr;
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, geglu);
-    if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
+    if (g.splitk > 1) { const size_t off = a_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); g.sk_count = sk_counters(); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * (geglu ? g.N / 2 : g.N) * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
@@ -546,7 +556,7 @@ void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, 
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = Y.valid ? ptr(Y) : nullptr; g.ldc = Y.ld; g.Cf = Cf; g.ldcf = ldcf;
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, false);
-    if (g.splitk > 1) { const size_t off = a_alloc((size_t)g.splitk * g.M * g.N * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); }
+    if (g.splitk > 1) { const size_t off = a_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); g.sk_count = sk_counters(); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)B * Hin * Win * Cin + (double)g.N * g.K + (double)g.M * g.N * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,1>", dt == DT_BF16 ? "bf16" : "f16");
@@ -1163,7 +1173,7 @@ int64_t Engine::n_launches() const {
     int64_t n = 0;
     for (const Op& o : ops) {
         if (o.kind == OP_GN) n += o.gn.stats_chunks > GN_NCHUNK ? 2 : (o.gn.stats_chunks > 0 ? 1 : 2);      // fold + apply / apply / statistics + apply
-        else n += (o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1)) ? 2 : 1;
+        else n += (o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1 && !gemm_sk_fixup(o.g))) ? 2 : 1;
     }
     return n;
 }

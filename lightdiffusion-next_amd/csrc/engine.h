@@ -121,6 +121,8 @@ public:
     // one CFG evaluation: x [B] is read by both halves of the [uncond; cond] batch (cond.py:186-226), sigma is one host scalar for every sample
     int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st);
     float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;
+    unsigned* d_sk_count = nullptr;                       // split-K tile counters (sk_counters()): one zeroed buffer per engine, every launch leaves it zeroed
+    unsigned* sk_counters();
     int plan(int B2, int h, int w, int Mc);
     int64_t n_launches() const;
     int64_t n_graph_captures = 0, n_graph_replays = 0;      // ldx_graph_stats (tests: the sampler loops must replay, not re-capture)

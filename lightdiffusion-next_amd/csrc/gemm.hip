@@ -620,9 +620,12 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
 }
 
 template <typename T>
-static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
+static void launch_gemm_t(const GemmArgs& a0, hipStream_t s) {
+    GemmArgs a = a0;
+    if (!gemm_sk_fixup(a)) a.sk_count = nullptr;        // the kernels reduce in place iff sk_count is set
     const int S = (a.splitk > 1 && a.ws && !a.geglu) ? a.splitk : 1;
     if (a.mode == 0) launch_gemm_mode<T, 0>(a, S, s); else launch_gemm_mode<T, 1>(a, S, s);
+    if (S > 1 && a.sk_count) return;                    // reduced by the last workgroup of every tile
     if (S > 1 && a.gn_partial) {       // reduce + GroupNorm statistics (gemm_gn_fuse set the geometry)
         int R = 1;
         const int nchunk = splitk_gn_geom(a, a.gn_hw, a.gn_G, a.gn_nchunk, &R);
@@ -635,12 +638,23 @@ static void launch_gemm_t(const GemmArgs& a, hipStream_t s) {
     }
 }
 
+bool gemm_sk_fixup(const GemmArgs& a) {
+    // OPT-IN (LDX_SK_FIXUP=1): measured on the SD1.5 1024^2 step, same box, round 4: reduce launches 14.55 / 14.71 ms, in-kernel reduction up to
+    // S = 2: 14.73 (neutral), up to S = 3 / 4: 14.69 / 14.84 (+0.13 ms) — the last arriver's S serial slab reads sit in the tail of the launch,
+    // while the reduce kernel spreads the same bytes over the whole chip (and also emits the GroupNorm partials).
+    static const bool off = !(getenv("LDX_SK_FIXUP") && atoi(getenv("LDX_SK_FIXUP")) != 0);
+    static const int max_s = getenv("LDX_SK_FIXUP_MAX") ? atoi(getenv("LDX_SK_FIXUP_MAX")) : SK_FIXUP_MAX_S;
+    if (off || !a.sk_count || !a.ws || a.splitk < 2 || a.splitk > max_s || a.geglu) return false;
+    return (long)((a.M + 63) / 64) * ((a.N + 31) / 32) <= SK_COUNTERS;      // an upper bound on the tile count of any tile shape
+}
+
 // Planner query (GemmArgs::gn_partial): which tile will launch_gemm_mode pick for `a`, and can that tile's epilogue produce the consumer
 // GroupNorm's statistics?  Mirrors launch_gemm_mode's mapping from gemm_tile() to an instantiation.  LDX_GN_FUSE=0 switches the fusion off.
 int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
     static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
     if (off || a.f8 || a.C8 || a.geglu || a.ln_c1 || !a.C || G <= 0 || a.N % G || a.N % 4 || HW <= 0 || a.M % HW) return 0;
-    if (a.splitk > 1 && a.ws) {        // split-K: the reduce launch produces the statistics (splitk_reduce_gn_kernel)
+    const bool fix = gemm_sk_fixup(a);        // in-kernel split-K reduction: the last workgroup of a tile runs the ordinary epilogue, statistics included
+    if (a.splitk > 1 && a.ws && !fix) {        // split-K with a reduce launch: that launch produces the statistics (splitk_reduce_gn_kernel)
         static const bool sk_off = getenv("LDX_GN_FUSE_SPLITK") && atoi(getenv("LDX_GN_FUSE_SPLITK")) == 0;
         int R = 1;
         const int nchunk = sk_off ? 0 : splitk_gn_geom(a, HW, G, max_chunks, &R);
@@ -649,7 +663,7 @@ int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
         return nchunk;
     }
     const int cpg = a.N / G;
-    const TileSel t = gemm_tile(a.M, a.N, a.K, false, 1, true, a.mode == 0);
+    const TileSel t = gemm_tile(a.M, a.N, a.K, false, fix ? a.splitk : 1, true, a.mode == 0);
     int bm, bn;
     if (t.bm == 256 && t.bn > 128) { bm = 256; bn = t.bn; }
     else if (t.bm == 256) { bm = 256; bn = 128; }

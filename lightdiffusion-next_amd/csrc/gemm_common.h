@@ -60,21 +60,74 @@ template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, 
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
                                               const int l15, const int g4, const int split, const int S,
                                               const float* lnm, const float* lnr, const uint2 (&rpre)[NR], const bool use_rpre) {
-    // ---- split-K: raw fp32 partials to the workspace, epilogue happens in splitk_reduce_kernel ----
+    // ---- split-K: raw fp32 partials to the workspace.  Without p.sk_count the epilogue happens in splitk_reduce_kernel (a second launch).
+    // With it (round 4; gemm_sk_fixup) the LAST workgroup to finish a tile reduces in place and carries on into the fused epilogue below — no
+    // reduce launch, and the tile feeds the consumer GroupNorm's statistics like any other.  The recipe is the guide's counter form of the
+    // agent-scope hand-off (cdna_hip_programming.md section 5, "In-launch split-K reduction"), in its write-through variant:
+    //   * every split workgroup writes its accumulators to a PRIVATE slab of the (tile, split) pair, lane-linear — each wave-instruction is one
+    //     contiguous 1 KiB store of 16 bytes per lane — with sc1 (write-through) stores: they reach memory without any L2 write-back fence.
+    //     (Round 3 tried the row-major [S][M][N] layout with 8-byte agent-scope atomics — 2.7x the cost per byte and four partial lines per
+    //     instruction: 16.4 -> 17.1 ms per step — and a __threadfence() pair, which writes back and invalidates a whole XCD L2 per workgroup.)
+    //   * every wave waits for its stores' acknowledgements (vmcnt(0)), the workgroup meets at a barrier, one lane takes a relaxed agent-scope
+    //     ticket; the workgroup that draws S - 1 resets the counter and reads ALL S slabs (its own too: the sum does not depend on who is last)
+    //     in split order with sc1 loads, 16 bytes per lane, MI * NJ loads in flight per slab.
+    // Placement-independent: nothing assumes which XCD a split runs on.
     if (S > 1) {
-        float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
+        if (p.sk_count == nullptr) {
+            float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
-        for (int i = 0; i < MI; ++i) {
-            const int m = m0 + wm * (BM / WM) + i * 16 + l15;
-            if (m >= p.M) continue;
+            for (int i = 0; i < MI; ++i) {
+                const int m = m0 + wm * (BM / WM) + i * 16 + l15;
+                if (m >= p.M) continue;
 #pragma unroll
-            for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
-                if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
-                else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+                    if (n + 3 < p.N) *(float4*)(ws + (size_t)m * p.N + n) = make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    else for (int r = 0; r < 4 && n + r < p.N; ++r) ws[(size_t)m * p.N + n + r] = acc[i][j][r];
+                }
             }
+            return;
         }
-        return;
+        extern __shared__ __attribute__((aligned(16))) char smem_ep[];
+        const int tile = (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN;
+        constexpr int SLAB = BM * BN;                                   // floats
+        const int lane_off = (((wm * 2 + wn) * MI * NJ) * 64 + (g4 * 16 + l15)) * 16;      // bytes; + (i * NJ + j) * 1024
+        {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + ((size_t)tile * S + split) * SLAB), 0, SLAB * 4, 0x00020000);
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(__attribute__((ext_vector_type(4))) unsigned, acc[i][j]), rs, lane_off + (i * NJ + j) * 1024, 0, 16 /* sc1 */);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");               // this wave's slab stores are acknowledged
+        volatile int& sk_last = *(volatile int*)(smem_ep + 8192);      // in the (idle) staging ring, clear of the statistics stage's first 5 KiB
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned old = __hip_atomic_fetch_add(p.sk_count + tile, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const bool last = old == (unsigned)(S - 1);
+            if (last) __hip_atomic_store(p.sk_count + tile, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // left at zero for the next launch
+            sk_last = last;
+        }
+        __syncthreads();
+        if (!sk_last) return;
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int sp = 0; sp < S; ++sp) {
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ws + ((size_t)tile * S + sp) * SLAB), 0, SLAB * 4, 0x00020000);
+            f32x4 t[MI][NJ];
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    t[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, lane_off + (i * NJ + j) * 1024, 0, 16 /* sc1 */));
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] += t[i][j];
+        }
     }
     // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
     if (p.C8) {

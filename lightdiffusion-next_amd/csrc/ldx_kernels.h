@@ -70,7 +70,11 @@ struct GemmArgs {
     // sum / sum of squares from its A fragments and stores  rstd[m] * (acc - mean[m] * ln_c1[n]) + bias[n]  (then GEGLU etc.)
     const float* ln_c1; float ln_eps;
     int splitk; float* ws;         // splitk > 1: K range split over `splitk` workgroups per tile; fp32 partials go to
-                                   // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue
+                                   // ws[splitk][M][N] and a second kernel reduces them and applies the epilogue ...
+    unsigned* sk_count;            // ... unless gemm_sk_fixup(a): sk_count points at zeroed per-tile counters (SK_COUNTERS of them, left at zero by every
+                                   // launch) and splitk <= SK_FIXUP_MAX_S: then the partials go to private per-(tile, split) slabs — ws needs
+                                   // gemm_sk_ws_floats() floats — and the LAST workgroup to finish a tile sums them in split order and runs the fused
+                                   // epilogue itself (round 4: no reduce launch; gemm_common.h)
     // gn_partial != null: the consumer of C is a GroupNorm over the same [B][gn_hw][N] tensor (gn_cpg channels per group, gn_G groups): every
     // tile also writes the sum / sum of squares of the 16-bit values it stores, per group, to gn_partial[b][tile row][group][2] with
     // gn_nchunk tile rows per batch image — GroupNormArgs::partial's layout, so the GroupNorm skips its statistics pass (one full read of the
@@ -84,6 +88,10 @@ void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
 // two independent plain GEMMs (mode 0, no split-K / GEGLU, both 16-bit or both MX) as one launch of 128x128 tiles
 void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s);
 int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
+constexpr int SK_FIXUP_MAX_S = 4;                          // in-kernel fix-up up to this many splits (the last arriver reads S slabs back to back); above: reduce launch
+constexpr int SK_COUNTERS = 8192;                          // per-tile counters a caller keeps for it
+inline size_t gemm_sk_ws_floats(int M, int N, int S) { return (size_t)S * ((size_t)M + 255) * ((size_t)N + 255); }      // slabs of whole tiles (tile <= 256 x 256), or the [S][M][N] layout
+bool gemm_sk_fixup(const GemmArgs& a);                     // will launch_gemm(a) reduce inside the kernel?  (opt-in: LDX_SK_FIXUP=1; measured slower than the reduce launch)
 // 256-row ping-pong tiles (gemm_pp.hip; chosen by launch_gemm's cost model): bn = 128 / 160 / 256 tile width, lnf = GemmArgs::ln_c1 fold, S = K splits
 void launch_gemm_pp(const GemmArgs& a, int bn, bool lnf, int S, DType dt, hipStream_t s);
 void launch_gemm_pp2(const GemmArgs& a, const GemmArgs& b, int bn, DType dt, hipStream_t s);

@@ -41,3 +41,117 @@ def gather_latents(x_local: torch.Tensor, total: int, dist=None):
         lo, hi = shard_bounds(total, r, world)
         out.append(chunks[r][: hi - lo])
     return torch.cat(out, dim=0)
+
+
+# ------------------------------------------------------------------------------------------------------------
+# Direct RCCL path (round 4): the one collective of a generation without torch.distributed in the data path.
+# ctypes on librccl.so (RCCL exports the NCCL API): ncclGetUniqueId on rank 0, the 128-byte id handed to the other ranks through a FILE
+# (atomic rename; the launcher exports LDX_RCCL_ID_FILE) or any callable the caller supplies, ncclCommInitRank, then ncclAllGather on the
+# caller's HIP stream straight from / into device pointers.  Same padding / slicing as gather_latents above, so both paths return equal tensors.
+import ctypes as _C
+import os as _os
+import time as _time
+
+NCCL_UNIQUE_ID_BYTES = 128
+_NCCL_FLOAT32 = 7          # ncclDataType_t: ncclFloat32 (nccl.h)
+
+
+class _NcclUniqueId(_C.Structure):
+    _fields_ = [("internal", _C.c_char * NCCL_UNIQUE_ID_BYTES)]
+
+
+def load_rccl(path: str = None):
+    """librccl.so with the four entry points' signatures set.  Raises OSError if the library is missing: there is no fallback."""
+    lib = _C.CDLL(path or _os.environ.get("LDX_RCCL_LIB", "librccl.so"))
+    lib.ncclGetUniqueId.argtypes = [_C.POINTER(_NcclUniqueId)]
+    lib.ncclCommInitRank.argtypes = [_C.POINTER(_C.c_void_p), _C.c_int, _NcclUniqueId, _C.c_int]
+    lib.ncclAllGather.argtypes = [_C.c_void_p, _C.c_void_p, _C.c_size_t, _C.c_int, _C.c_void_p, _C.c_void_p]
+    lib.ncclCommDestroy.argtypes = [_C.c_void_p]
+    lib.ncclGetErrorString.argtypes = [_C.c_int]
+    lib.ncclGetErrorString.restype = _C.c_char_p
+    for f in (lib.ncclGetUniqueId, lib.ncclCommInitRank, lib.ncclAllGather, lib.ncclCommDestroy):
+        f.restype = _C.c_int
+    return lib
+
+
+def exchange_unique_id_file(path: str, rank: int, make_id, timeout_s: float = 120.0) -> bytes:
+    """Rank 0 calls make_id() -> 128 bytes and publishes them at `path` (written to a temporary name, then renamed: readers never see a partial
+    file); every other rank waits for the file.  Returns the id on every rank."""
+    if rank == 0:
+        uid = bytes(make_id())
+        assert len(uid) == NCCL_UNIQUE_ID_BYTES, len(uid)
+        tmp = f"{path}.tmp.{_os.getpid()}"
+        with open(tmp, "wb") as f:
+            f.write(uid)
+            f.flush()
+            _os.fsync(f.fileno())
+        _os.replace(tmp, path)
+        return uid
+    t0 = _time.monotonic()
+    while True:
+        try:
+            with open(path, "rb") as f:
+                uid = f.read()
+            if len(uid) == NCCL_UNIQUE_ID_BYTES:
+                return uid
+        except FileNotFoundError:
+            pass
+        if _time.monotonic() - t0 > timeout_s:
+            raise TimeoutError(f"RCCL unique id did not appear at {path} within {timeout_s} s")
+        _time.sleep(0.01)
+
+
+class RcclComm:
+    """One RCCL communicator over the ranks of a node.  id_exchange(rank, make_id) -> bytes hands rank 0's unique id to everybody
+    (default: the file named by LDX_RCCL_ID_FILE)."""
+
+    def __init__(self, rank: int, world: int, id_exchange=None, lib=None):
+        self.rank, self.world = rank, world
+        self.lib = lib or load_rccl()
+
+        def make_id():
+            uid = _NcclUniqueId()
+            self._check(self.lib.ncclGetUniqueId(_C.byref(uid)), "ncclGetUniqueId")
+            return bytes(uid.internal)
+
+        if id_exchange is None:
+            path = _os.environ.get("LDX_RCCL_ID_FILE")
+            if not path:
+                raise RuntimeError("RcclComm: set LDX_RCCL_ID_FILE (a path every rank of the node can read) or pass id_exchange")
+            id_exchange = lambda r, mk: exchange_unique_id_file(path, r, mk)
+        raw = id_exchange(rank, make_id)
+        uid = _NcclUniqueId()
+        _C.memmove(_C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        self.comm = _C.c_void_p()
+        self._check(self.lib.ncclCommInitRank(_C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            raise RuntimeError(f"{what} failed: {self.lib.ncclGetErrorString(rc).decode()}")
+
+    def all_gather_latents(self, x_local: torch.Tensor, total: int, stream_ptr: int = None) -> torch.Tensor:
+        """gather_latents() through ncclAllGather: fp32 device tensors, equal padded chunks, then the true per-rank slices."""
+        assert x_local.is_cuda and x_local.dtype == torch.float32
+        per = (total + self.world - 1) // self.world
+        pad = torch.zeros((per,) + tuple(x_local.shape[1:]), dtype=torch.float32, device=x_local.device)
+        pad[: x_local.shape[0]] = x_local
+        recv = torch.empty((self.world * per,) + tuple(x_local.shape[1:]), dtype=torch.float32, device=x_local.device)
+        st = stream_ptr if stream_ptr is not None else torch.cuda.current_stream().cuda_stream
+        self._check(self.lib.ncclAllGather(_C.c_void_p(pad.data_ptr()), _C.c_void_p(recv.data_ptr()), pad.numel(), _NCCL_FLOAT32, self.comm, _C.c_void_p(st)),
+                    "ncclAllGather")
+        return unpad_gathered(recv, total, self.world)
+
+    def close(self):
+        if getattr(self, "comm", None):
+            self.lib.ncclCommDestroy(self.comm)
+            self.comm = None
+
+
+def unpad_gathered(recv: torch.Tensor, total: int, world: int) -> torch.Tensor:
+    """[world * per, ...] of equal padded chunks -> the true [total, ...] batch (rank r contributed shard_bounds(total, r, world))."""
+    per = recv.shape[0] // world
+    out = []
+    for r in range(world):
+        lo, hi = shard_bounds(total, r, world)
+        out.append(recv[r * per: r * per + (hi - lo)])
+    return torch.cat(out, dim=0)
