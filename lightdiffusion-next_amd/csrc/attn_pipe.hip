@@ -47,7 +47,7 @@ __device__ __forceinline__ ap_i32x2 ap_lds_read_tr16(const char* p) {
 }
 template <typename V> __device__ __forceinline__ ap_i32x4 ap_bits(const V& v) { return __builtin_bit_cast(ap_i32x4, v); }
 template <typename T> struct ApT;
-template <> struct ApT<__bf16>   { static constexpr int split = 256, expsh = 7, maxdl = 255; static constexpr float thr = 32.0f; };
+template <> struct ApT<__bf16>   { static constexpr int split = 256, expsh = 7, maxdl = 255; static constexpr float thr = 64.0f; };      // P <= 2^64: N * 2^64 * |v| stays far inside fp32
 template <> struct ApT<_Float16> { static constexpr int split = 2048, expsh = 10, maxdl = 31; static constexpr float thr = 15.0f; };
 
 // ---- QK^T MFMAs (32x32x16) with explicit register classes: S' in arch VGPRs, K / Q fragments in AGPRs.  First MFMA of a chain: C = 0.
@@ -95,7 +95,43 @@ template <int LO, int HI> constexpr auto ap_range() { return ap_range_impl<LO>(s
 template <int N> using ap_ic = std::integral_constant<int, N>;
 
 // ABL: timing ablations (wrong results; LDX_ATTN_PIPE_ABL, profiles/ubench): 1 no s_barrier, 2 no maximum, 8 no staging, 16 no fragment re-reads, 32 no exponentials
-template <typename T, int ABL>
+// max over the 64 keys of a block of ||k||_2 (x 1.002: rounding margin), one wave per (batch, head, block), lane = key.  With ||q c||_2 per query the
+// main kernel gets  s - m_ref <= ||q c|| * knorm[block] - m_ref  for every score of the block without looking at the scores.
+template <typename T>
+__global__ __launch_bounds__(256) void attn_knorm_kernel(const AttnArgs p) {
+    const int lane = threadIdx.x & 63, nblk = (p.Mk + 63) >> 6;
+    const long w = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (w >= (long)p.B * p.H * nblk) return;
+    const int blk = (int)(w % nblk), hb = (int)(w / nblk), h = hb % p.H, b = hb / p.H;
+    const int key = blk * 64 + lane;
+    float ss = 0.f;
+    if (key < p.Mk) {
+        const T* kp = (const T*)p.K + ((long)b * p.Mk + key) * p.ldk + h * p.D;
+        for (int ch = 0; ch < p.D / 8; ++ch) {
+            float f[8]; unpack8<T>(*(const uint4*)(kp + ch * 8), f);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ss = fmaf(f[e], f[e], ss);
+        }
+    }
+    ss = wave_max(ss);
+    if (lane == 0) p.knorm_ws[w] = sqrtf(ss) * 1.002f;
+}
+
+// Softmax pieces per MFMA gap (32 per slot).  A piece costs about 20 issue cycles (two quarter-rate exponentials and a pack), an LDS fragment read 8,
+// a staging store 13, a staging load with its address arithmetic about 24; the tables give every gap a similar total.
+template <bool KB> struct ApSched {
+    static constexpr int BAR = 8;                    // the slot's barrier sits in front of gap BAR
+    static constexpr int n(int g) {
+        constexpr int kb[28] = {1, 1, 1, 1, 2, 1, 2, 1,  1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1,  2, 1, 1, 1, 2, 1};
+        constexpr int ex[28] = {1, 1, 1, 1, 2, 2, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 1, 1, 1, 1, 1, 1,  1, 1, 2, 2};      // exact maximum: its blocks sit in gaps 16-25
+        return KB ? kb[g] : ex[g];
+    }
+    static constexpr int first(int g) { int s = 0; for (int i = 0; i < g; ++i) s += n(i); return s; }      // first piece of gap g; first(28) == 32
+};
+static_assert(ApSched<true>::first(28) == 32 && ApSched<false>::first(28) == 32, "32 softmax pieces per slot");
+
+// KB: key-block bound (AttnArgs::knorm_ws): the per-score maximum is taken only for blocks whose bound exceeds the threshold
+template <typename T, int ABL, bool KB>
 __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const float thr) {
     constexpr int KROWB = 144, VROWB = 192, KVB = 64, D = 40, DCH = 5;
     constexpr int KBYTES = KVB * KROWB, VBYTES = KVB * VROWB;
@@ -127,10 +163,12 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     // Q fragments (B operand of QK^T): lane holds q = l31, d = 16 ks + 8 h2 .. +7, pre-multiplied by scale * log2(e) unless that is 1;
     // elements 0, 1 of qf[qt][2] on the h2 = 1 half (d = 40, 41) carry -m_ref
     ap_i32x4 qf[2][3];
+    float qn[2] = {0.f, 0.f};                        // KB: ||q c||_2 of the lane's query (x 1.002)
     const bool unit = fabsf(c - 1.0f) < 1e-6f;
 #pragma unroll
     for (int qt = 0; qt < 2; ++qt) {
         const int q = q0 + qt * 32 + l31;
+        float ss = 0.f;
 #pragma unroll
         for (int ks = 0; ks < 3; ++ks) {
             const int ch = 2 * ks + h2;
@@ -141,11 +179,20 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] = (T)((float)v[e] * c);
             }
+            if constexpr (KB) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+            }
             ap_i32x4 w = ap_bits(v);
             asm volatile("" : "+a"(w));
             qf[qt][ks] = w;
         }
+        if constexpr (KB) {
+            auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+            qn[qt] = sqrtf(__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * 1.002f;
+        }
     }
+    const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc((void*)(KB ? p.knorm_ws + (long)hb * nblk : nullptr), 0, KB ? nblk * 4 : 0, 0x00020000);
 
     // ---- staging: 640 16-byte chunks per slot (K tile 320 + V tile 320) over 256 threads in three rounds; the tile a round moves is wave-uniform
     //   round 0: K chunk tid;  round 1: wave 0: K chunk 256 + lane, waves 1-3: V chunk tid - 64;  round 2: waves 0, 1: V chunk tid + 192
@@ -165,32 +212,28 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         }
     }
     const unsigned kstep = (unsigned)(KVB * p.ldk * 2), vstep = (unsigned)(KVB * p.ldv * 2);      // one batch of K / V is far below 4 GiB
-    uint4 rs0, rs1, rs2;
+    uint4 rsA[3], rsB[3];                            // two staging sets (named, statically indexed): the loads of slot t are stored in slot t + 1
     // tile indices are clamped to the last block: the tail slots re-stage it into ring slots nobody reads any more.  Buffer loads: the per-lane
     // chunk offset in voffset, the tile's byte offset in soffset (SALU only)
     const __amdgpu_buffer_rsrc_t rK = __builtin_amdgcn_make_buffer_rsrc((void*)Kp, 0, (int)(((long)(p.Mk - 1) * p.ldk + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t rV = __builtin_amdgcn_make_buffer_rsrc((void*)Vp, 0, (int)(((long)(p.Mk - 1) * p.ldv + D) * 2), 0x00020000);
     const __amdgpu_buffer_rsrc_t r1 = r1k ? rK : rV;
     const unsigned step1 = r1k ? kstep : vstep;
-    auto gload1 = [&](int i, int kblk, int vblk) __attribute__((always_inline)) {
+    auto gload1 = [&](uint4 (&rs)[3], int i, int kblk, int vblk) __attribute__((always_inline)) {
         kblk = min(kblk, nblk - 1); vblk = min(vblk, nblk - 1);
         const auto v = i == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rK, gofs[0], kblk * kstep, 0)
                      : (i == 1 ? __builtin_amdgcn_raw_buffer_load_b128(r1, gofs[1], (r1k ? kblk : vblk) * step1, 0)
                                : __builtin_amdgcn_raw_buffer_load_b128(rV, gofs[2], vblk * vstep, 0));
-        const uint4 u = make_uint4(v[0], v[1], v[2], v[3]);
-        if (i == 0) rs0 = u; else if (i == 1) rs1 = u; else rs2 = u;
+        rs[i] = make_uint4(v[0], v[1], v[2], v[3]);
     };
-    auto gload = [&](int kblk, int vblk) __attribute__((always_inline)) { gload1(0, kblk, vblk); gload1(1, kblk, vblk); gload1(2, kblk, vblk); };
+    auto gload = [&](uint4 (&rs)[3], int kblk, int vblk) __attribute__((always_inline)) { gload1(rs, 0, kblk, vblk); gload1(rs, 1, kblk, vblk); gload1(rs, 2, kblk, vblk); };
     // asm with an AGPR data operand: the staging loads then land in AGPRs (with a VGPR home hipcc spilled them to AGPRs right behind the load,
     // i.e. vmcnt(0) three times per slot); hipcc still sees the load -> use dependency and places the vmcnt wait in front of the store
-    auto lstore1 = [&](int i, int slot) __attribute__((always_inline)) {
-        const ap_i32x4 w = ap_bits(i == 0 ? rs0 : (i == 1 ? rs1 : rs2));
+    auto lstore1 = [&](const uint4 (&rs)[3], int i, int slot) __attribute__((always_inline)) {
+        const ap_i32x4 w = ap_bits(rs[i]);
         asm volatile("ds_write_b128 %0, %1" :: "v"(lofs[slot][i]), "a"(w) : "memory");
     };
-    auto lstore = [&](int slot) __attribute__((always_inline)) { lstore1(0, slot); lstore1(1, slot); lstore1(2, slot); };
-    // K fragments (A operand of the asm QK^T MFMAs: AGPRs) and V^T fragments (A operand of the builtin PV MFMAs: either class) are read by
-    // builtins, so hipcc places the lgkmcnt waits.  (Asm reads with AGPR outputs were tried: the two 64-bit halves of a V^T fragment are glued by
-    // a REG_SEQUENCE, and hipcc copied them — before the data had arrived, which it cannot know — so that form is unsafe.)
+    auto lstore = [&](const uint4 (&rs)[3], int slot) __attribute__((always_inline)) { lstore1(rs, 0, slot); lstore1(rs, 1, slot); lstore1(rs, 2, slot); };
     V8 kf[3][2];
     auto kread1 = [&](int ks, int kt, int slot) __attribute__((always_inline)) {
         kf[ks][kt] = as_v8<T>(*(const uint4*)(smem + slot * KBYTES + (kt * 32 + l31) * KROWB + (2 * ks + h2) * 16));
@@ -231,13 +274,14 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     };
     // softmax piece k in [0, 32): dword k of P(t): (qt, st, w) = (k >> 4, (k >> 2) & 3, k & 3) = elements 2 w, 2 w + 1 of pf[qt][st], from
     // S' registers 8 (st & 1) + 2 w (+1) of tile (st >> 1, qt); its pack is issued with piece k + 1 (ap_piece), the last one by ap_pack
-    float ex[3] = {0.f, 0.f, 0.f}, ey[3] = {0.f, 0.f, 0.f};      // results of the pieces in flight: pair k % 3 (the pack trails by two pieces, see ap_piece)
+    constexpr int LAG = 3;                              // the pack trails by LAG pieces, the pieces rotate through LAG + 1 temporary pairs (see ap_piece)
+    float ex[LAG + 1] = {0.f, 0.f, 0.f, 0.f}, ey[LAG + 1] = {0.f, 0.f, 0.f, 0.f};
     auto piece = [&](auto K, const f32x16 (&s)[2][2], ap_i32x4 (&pf)[2][4]) __attribute__((always_inline)) {
         constexpr int k = decltype(K)::value, qt = k >> 4, st = (k >> 2) & 3, w = k & 3;
         const float a = s[st >> 1][qt][8 * (st & 1) + 2 * w], bb = s[st >> 1][qt][8 * (st & 1) + 2 * w + 1];
         if constexpr (ABL & 32) { int r; asm volatile("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(bb)); pf[qt][st][w] = r; }
-        else if constexpr (k < 2) ap_piece0(a, bb, ex[k], ey[k]);
-        else { constexpr int j = k - 2; pf[j >> 4][(j >> 2) & 3][j & 3] = ap_piece<T>(a, bb, ex[k % 3], ey[k % 3], ex[j % 3], ey[j % 3]); }
+        else if constexpr (k < LAG) ap_piece0(a, bb, ex[k], ey[k]);
+        else { constexpr int j = k - LAG; pf[j >> 4][(j >> 2) & 3][j & 3] = ap_piece<T>(a, bb, ex[k % (LAG + 1)], ey[k % (LAG + 1)], ex[j % (LAG + 1)], ey[j % (LAG + 1)]); }
     };
     // maximum of S'(t+1): block m in [0, 8): (qt, kt, half) = (m >> 2, (m >> 1) & 1, m & 1), eight registers each
     float mx[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -265,17 +309,18 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     };
 
     // ---- prologue: K(0), K(1), V(0) staged; S(0) against m_ref = 0; m_ref := ceil(maximum of block 0); K(1) fragments in registers, K(2) in ring slot 0
-    gload(0, 0); __syncthreads(); lstore(0);
-    gload(1, 0); lstore(1);                          // (V(0) goes to both V ring slots: a staging round always moves both tiles)
+    gload(rsA, 0, 0); __syncthreads(); lstore(rsA, 0);
+    gload(rsA, 1, 0); lstore(rsA, 1);                // (V(0) goes to both V ring slots: a staging round always moves both tiles)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     kread(0);
     ap_for(ap_range<0, 12>(), [&](auto I) __attribute__((always_inline)) { qk1(I, sA); });
     kread(1);
-    gload(2, 0);
+    gload(rsA, 2, 0);
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the asm MFMAs' results settle before the VALU reads them
     __syncthreads();                                 // every wave has read K(0) from ring slot 0
-    lstore(0);
+    lstore(rsA, 0);
+    gload(rsB, 3, 1);                                // what slot 0 stores (K(3), V(1)): every slot stores the tiles loaded a slot earlier
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();
     ap_for(ap_range<0, 2>(), [&](auto QT) __attribute__((always_inline)) {
@@ -291,47 +336,49 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         set_ref(QT, mr);
     });
 
-    // ---- slot t.  Matrix pipe: QK^T(t+1) (gaps 0-11), PV(t-1) (gaps 12-27).  VALU: S'(t) -> P(t) (32 pieces), maximum of S'(t+1) (gaps 16-25).
-    // One barrier between the two matrix phases: tiles stored in the second half of slot t - 1 become readable behind it (K(t+2) fragments right
-    // after it, V(t) fragments later), and this slot's stores overwrite ring slots whose last readers (second half of slot t - 1) every wave has
-    // passed before it arrives.  Raw s_barrier + lgkmcnt(0) only: the staging loads issued at the top of the slot stay in flight across it.
-    auto slot = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], ap_i32x4 (&pp)[2][4], ap_i32x4 (&pc)[2][4], V8 (&vfc)[4][2], V8 (&vfn)[4][2], auto PAR) __attribute__((always_inline)) {
+    // ---- slot t.  Matrix pipe: QK^T(t+1) (gaps 0-11), PV(t-1) (gaps 12-27).  VALU: S'(t) -> P(t) (32 pieces), maximum (or bound) of S'(t+1).
+    // One barrier per slot: tiles stored in slot t - 1 (gaps 17-21) become readable behind it (V(t) fragments right after it, K(t+2) fragments
+    // from gap 16), and this slot's stores overwrite ring slots whose last readers (slot t - 1, behind its barrier) every wave has passed before
+    // it arrives.  Raw s_barrier + lgkmcnt(0) only: the staging loads issued at the top of the slot stay in flight across it.
+    auto slot = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], ap_i32x4 (&pp)[2][4], ap_i32x4 (&pc)[2][4], V8 (&vfc)[4][2], V8 (&vfn)[4][2], uint4 (&rsl)[3], const uint4 (&rss)[3], auto PAR) __attribute__((always_inline)) {
         constexpr int par = decltype(PAR)::value;    // t & 1: ring slots are compile-time constants
-        __builtin_amdgcn_sched_barrier(0);
-        ap_for(ap_range<0, 12>(), [&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            qk1(I, sn);
-            if constexpr (i < 3 && !(ABL & 8)) gload1(i, t + 3, t + 1);
-            // pieces 0 .. 17: two in even gaps, one in odd gaps
-            constexpr int k0 = 3 * (i >> 1) + 2 * (i & 1);
-            piece(ap_ic<k0>{}, sc, pc);
-            if constexpr (!(i & 1)) piece(ap_ic<k0 + 1>{}, sc, pc);
+        float kn = 0.f, bm0 = 0.f, bm1 = 0.f;
+        // gap g: MFMA g (QK^T(t+1) for g < 12, PV(t-1) after), then its fillers from the schedule (ApSched): staging loads in gaps 0-2, the slot's
+        // barrier behind gap BAR - 1, V(t) fragment reads (into the other fragment set) in the eight gaps from BAR on, K(t+2) fragment reads in gaps
+        // 16-21 (this slot's QK^T MFMAs are issued), the staging stores in gaps 17 / 19 / 21, the 32 softmax pieces spread so that every gap costs
+        // about the same (a gap cannot be shorter than its MFMA's 32 cycles, and the wave stalls in a gap that is lighter).
+        auto gap = [&](auto G) __attribute__((always_inline)) {
+            constexpr int g = decltype(G)::value;
+            using S = ApSched<KB>;
+            if constexpr (g == S::BAR) {
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
+                asm volatile("" ::: "memory");
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (g < 12) qk1(G, sn); else pv1(ap_ic<g - 12>{}, pp, vfc);
+            if constexpr (g < 3 && !(ABL & 8)) gload1(rsl, g, t + 4, t + 2);                                              // stored in slot t + 1 (a whole slot of latency cover)
+            if constexpr (KB && g == 3) kn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rN, 0, min(t + 1, nblk - 1) * 4, 0));      // max ||k|| of block t + 1 (same for every lane)
+            if constexpr (g >= S::BAR && g < S::BAR + 8 && !(ABL & 16)) vread1(vfn, (g - S::BAR) >> 1, (g - S::BAR) & 1, par);      // V(t), staged in slot t - 1
+            if constexpr (g >= 16 && g < 22 && !(ABL & 16)) kread1((g - 16) >> 1, (g - 16) & 1, par);                  // K(t+2), staged in slot t - 1
+            if constexpr ((g == 17 || g == 19 || g == 21) && !(ABL & 8)) lstore1(rss, (g - 17) >> 1, par ^ 1);          // K(t+3), V(t+1), loaded in slot t - 1
+            ap_for(ap_range<S::first(g), S::first(g + 1)>(), [&](auto K) __attribute__((always_inline)) { piece(K, sc, pc); });
+            if constexpr (!KB) {
+                if constexpr (g >= 16 && g < 24 && !(ABL & 2)) maxblk(ap_ic<g - 16>{}, sn);                      // S'(t+1): its last MFMA issued in gap 11
+                if constexpr (g == 24 && !(ABL & 2)) bm0 = bmax(0);
+                if constexpr (g == 25 && !(ABL & 2)) bm1 = bmax(1);
+            } else if constexpr (g == 24) {          // bound on S'(t+1) = s - m_ref from the norms: ||q c|| * max ||k|| - m_ref
+                bm0 = fmaf(qn[0], kn, -mref[0]); bm1 = fmaf(qn[1], kn, -mref[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
-        });
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        if constexpr (!(ABL & 1)) __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
+        };
         __builtin_amdgcn_sched_barrier(0);
-        float bm0 = 0.f, bm1 = 0.f;
-        ap_for(ap_range<12, 28>(), [&](auto I) __attribute__((always_inline)) {
-            constexpr int i = decltype(I)::value;
-            pv1(ap_ic<i - 12>{}, pp, vfc);           // P(t-1) x V(t-1)
-            if constexpr (i < 20 && !(ABL & 16)) vread1(vfn, (i - 12) >> 1, (i - 12) & 1, par);                             // V(t), staged in slot t - 1, into the other fragment set
-            if constexpr (i >= 18 && i < 24 && !(ABL & 16)) kread1((i - 18) >> 1, (i - 18) & 1, par);                       // K(t+2), staged in slot t - 1 (this slot's QK^T MFMAs are issued)
-            if constexpr ((i == 19 || i == 21 || i == 23) && !(ABL & 8)) lstore1((i - 19) >> 1, par ^ 1);                    // K(t+3), V(t+1)
-            // pieces 18 .. 23 in gaps 12-15 (2, 1, 2, 1); 24 .. 27 in gaps 16, 18, 20, 22; 28 .. 31 in gaps 24-27
-            if constexpr (i < 16) { constexpr int k0 = 18 + 3 * ((i - 12) >> 1) + 2 * (i & 1); piece(ap_ic<k0>{}, sc, pc); if constexpr (!(i & 1)) piece(ap_ic<k0 + 1>{}, sc, pc); }
-            else if constexpr (i < 24) { if constexpr (!(i & 1)) piece(ap_ic<24 + ((i - 16) >> 1)>{}, sc, pc); }
-            else piece(ap_ic<28 + (i - 24)>{}, sc, pc);
-            if constexpr (i >= 16 && i < 24 && !(ABL & 2)) maxblk(ap_ic<i - 16>{}, sn);                          // S'(t+1): its last MFMA issued in gap 11
-            if constexpr (i == 24 && !(ABL & 2)) bm0 = bmax(0);
-            if constexpr (i == 25 && !(ABL & 2)) bm1 = bmax(1);
-            __builtin_amdgcn_sched_barrier(0);
-        });
-        pc[1][3][2] = ap_pack<T>(ex[30 % 3], ey[30 % 3]);      // packs of pieces 30, 31
-        pc[1][3][3] = ap_pack<T>(ex[31 % 3], ey[31 % 3]);
+        ap_for(ap_range<0, 28>(), gap);
+        pc[1][3][1] = ap_pack<T>(ex[29 % (LAG + 1)], ey[29 % (LAG + 1)]);      // packs of pieces 29, 30, 31
+        pc[1][3][2] = ap_pack<T>(ex[30 % (LAG + 1)], ey[30 % (LAG + 1)]);
+        pc[1][3][3] = ap_pack<T>(ex[31 % (LAG + 1)], ey[31 % (LAG + 1)]);
         // rare path: some query's S'(t+1) exceeds thr: raise its reference by the integer dl BEFORE the exponentials of block t + 1 are taken
-        if (__builtin_amdgcn_ballot_w64(fmaxf(bm0, bm1) > thr) != 0) {
+        auto raise_reference = [&]() __attribute__((always_inline)) {
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // PV(t-1) has landed in O
             ap_for(ap_range<0, 2>(), [&](auto QT) __attribute__((always_inline)) {
                 constexpr int qt = decltype(QT)::value;
@@ -348,11 +395,24 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
                 for (int r = 0; r < 16; ++r) { sn[0][qt][r] -= dl; sn[1][qt][r] -= dl; }
                 set_ref(QT, mnew);
             });
+        };
+        if constexpr (KB) {
+            // ONE branch on the common path: the bound does not prove the block safe for some query of this wave -> the exact maximum (what the other
+            // variant does in every slot), and only inside that the threshold test proper.  (As two consecutive branches hipcc hoisted the rare path's
+            // AGPR -> VGPR copies of O in front of the first one: 64 v_accvgpr_read per slot.)
+            if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                ap_for(ap_range<0, 8>(), [&](auto M) __attribute__((always_inline)) { maxblk(M, sn); });
+                bm0 = bmax(0); bm1 = bmax(1);
+                if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) raise_reference();
+            }
+        } else {
+            if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) raise_reference();
         }
     };
     for (int t = 0; t < nblk; t += 2) {
-        slot(t, sA, sB, pA, pB, vfA, vfB, ap_ic<0>{});
-        slot(t + 1, sB, sA, pB, pA, vfB, vfA, ap_ic<1>{});
+        slot(t, sA, sB, pA, pB, vfA, vfB, rsA, rsB, ap_ic<0>{});
+        slot(t + 1, sB, sA, pB, pA, vfB, vfA, rsB, rsA, ap_ic<1>{});
     }
     ap_for(ap_range<0, 16>(), [&](auto J) __attribute__((always_inline)) { pv1(J, pA, vfA); });      // P(nblk-1) (nblk even: written by the odd slot into pA) x V(nblk-1)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");
@@ -389,7 +449,14 @@ template <typename T, int ABL = 0>
 static void launch_attn40p(const AttnArgs& a, hipStream_t s, float thr) {
     const size_t lds = 2 * 64 * (144 + 192);
     dim3 grid((a.Nq / 256) * a.H * a.B);
-    hipLaunchKernelGGL((attn40p_kernel<T, ABL>), grid, dim3(256), lds, s, a, thr);
+    static const bool kb_off = getenv("LDX_ATTN_PIPE_KB") && atoi(getenv("LDX_ATTN_PIPE_KB")) == 0;      // experiment switch: exact maximum on every block
+    if (a.knorm_ws && !kb_off && ABL == 0) {
+        const long waves = (long)a.B * a.H * ((a.Mk + 63) / 64);
+        hipLaunchKernelGGL((attn_knorm_kernel<T>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+        hipLaunchKernelGGL((attn40p_kernel<T, ABL, true>), grid, dim3(256), lds, s, a, thr);
+    } else {
+        hipLaunchKernelGGL((attn40p_kernel<T, ABL, false>), grid, dim3(256), lds, s, a, thr);
+    }
 }
 
 // thr_override: NaN = the type's default (tests force the rare path with small values)

@@ -461,6 +461,7 @@ int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void*
                      float scale, int causal, int dtype, void* stream) {
     if (!Q || !K || !V || !O || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160)"); return LDX_EINVAL; }
     AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal, nullptr, 0, 0};
+    if (attn_pipe_ok(a)) a.knorm_ws = op_workspace((size_t)B * H * ((Mk + 63) / 64));      // (shared single-op scratch: one stream per device, include/ldx.h)
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention");
 }

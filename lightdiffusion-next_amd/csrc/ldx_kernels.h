@@ -125,6 +125,9 @@ struct AttnArgs {
     // O8 != null (only when attention_mx_out_ok(a)): the output is written as MX fp8 instead of 16-bit O — bytes
     // O8[b*Nq + n][h*D + d] (row stride ldo8) and, D being 128, one scale dword per (row, head): SO[h][b*Nq + n] (row stride so_ld)
     void* O8; int ldo8; uint32_t* SO; int so_ld;
+    // optional workspace of B * H * ceil(Mk / 64) floats (attn_pipe.hip): with it the pipelined D = 40 kernel proves most key blocks safe from the
+    // norms of their keys (Cauchy-Schwarz) instead of taking the maximum of every score; null: the exact maximum on every block
+    float* knorm_ws;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
 // Software-pipelined D = 40 kernel (attn_pipe.hip, round 4): attn_pipe_ok() says whether it takes the shape (D = 40, Nq % 256 == 0, Mk % 128 == 0,

@@ -5,7 +5,7 @@ OUT=$ROOT/gpurun_out/pmc_attn_pipe.txt
 : > $OUT
 cd /tmp; export TMPDIR=/tmp
 if [ -n "$1" ]; then rocprofv3 -L 2>/dev/null | grep -o "SQ_[A-Z_0-9]*" | sort -u | tr '\n' ' ' > $ROOT/gpurun_out/sq_counters.txt; fi
-for which in 0 1 2; do
+for which in ${WHICH:-0 1}; do
   for set in "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU SQ_ACTIVE_INST_VALU" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY" "SQ_BUSY_CYCLES SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD" "SQ_ACTIVE_INST_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_LDS SQ_INST_CYCLES_SALU" "SQ_INSTS_MFMA SQ_INSTS_VALU_TRANS SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA"; do
     rm -rf /tmp/pm
     rocprofv3 --pmc $set -d /tmp/pm -o p --output-format csv -- $ROOT/profiles/ubench/attn_pipe_test 16384 4 $which > /tmp/pm.log 2>&1 || tail -3 /tmp/pm.log >> $OUT
