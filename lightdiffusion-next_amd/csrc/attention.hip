@@ -1021,6 +1021,18 @@ void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {
             return;
         }
     }
+    // D = 128 (Flux): the same pipeline (attn_pipe128.hip) when one round of its 256-query workgroups covers at least three quarters of the CUs.
+    // O8 (MX fp8 output) needs attention_mx_out_ok(), i.e. the attn32g D = 128 variant enabled: the callers' test, unchanged.
+    if (attn_pipe128_ok(a)) {
+        const char* e = getenv("LDX_ATTN_PIPE128");
+        const char* m = getenv("LDX_ATTN_PIPE_MINWG");
+        const long wgs = (long)(a.Nq / 256) * a.H * a.B;
+        if ((!e || atoi(e) != 0) && wgs >= (m ? atol(m) : 192)) {
+            const char* t = getenv("LDX_ATTN_PIPE_THR");
+            launch_attn_pipe128(a, dt, s, t ? (float)atof(t) : __builtin_nanf(""));
+            return;
+        }
+    }
     if (dt == DT_BF16) launch_attn_d<__bf16>(a, s); else launch_attn_d<_Float16>(a, s);
 }
 

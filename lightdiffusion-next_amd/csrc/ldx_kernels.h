@@ -134,6 +134,9 @@ void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
 // Mk >= 256, no mask / bias); thr_override = NaN keeps the type's rescale threshold (tests force the rare path with small values).
 bool attn_pipe_ok(const AttnArgs& a);
 void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
+// The same pipeline for D = 128 (attn_pipe128.hip: Flux joint attention), 16-bit or MX fp8 output (AttnArgs::O8)
+bool attn_pipe128_ok(const AttnArgs& a);
+void launch_attn_pipe128(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 
 // Cross-attention sub-block as one kernel (xattn_block.hip): H[m][:] += to_out(softmax(to_q(LayerNorm(H[m][:])) . K_b^T) . V_b) + bo, in place,
 // for m in [0, M), image b = m / N.  Wq / Wo: [C][C] 16-bit, row = output feature.  K / V: the projected context, rows b * Mk + key, head h at

@@ -1,9 +1,10 @@
 // Stand-alone check + A/B timing of the D = 40 attention kernels through the C ABI (no torch: a gpurun call spends its time on the GPU).
 //   build:  hipcc -O2 -std=c++17 profiles/ubench/attn_pipe_test.cpp -o profiles/ubench/attn_pipe_test -L lightdiffusion-next_amd -lldx -Wl,-rpath,'$ORIGIN/../../lightdiffusion-next_amd'
 //   run  :  profiles/ubench/attn_pipe_test [N_big] [reps]
-// 1. B1 H2 N512 (and N = 1024 with a score spike) against a double-precision reference on the rounded inputs, for attn32* (LDX_ATTN_PIPE=0), the
-//    pipelined kernel, and the pipelined kernel with the rescale path forced on every block (LDX_ATTN_PIPE_THR=-1000) or often (THR=0).
-// 2. B2 H8 N16384 D40 timing, the two kernels alternating, HIP events on the launch stream.
+//   run  :  profiles/ubench/attn_pipe_test [N_big] [reps] [only_variant] [D = 40 | 128]
+// 1. B1 H2 N512 (and N = 1024 with score spikes) against a double-precision reference on the rounded inputs, for attn32* (LDX_ATTN_PIPE=0,
+//    LDX_ATTN_PIPE128=0), the pipelined kernel, and the pipelined kernel with the rescale path taken often (LDX_ATTN_PIPE_THR=0 / 3 / -1000).
+// 2. timing, the two kernels alternating, HIP events on the launch stream: D = 40: B2 H8 N16384 (SD1.5 level 0); D = 128: B1 H24 N4352 (Flux).
 #include <hip/hip_runtime.h>
 #include <cmath>
 #include <cstdio>
@@ -65,9 +66,10 @@ int main(int argc, char** argv) {
     setenv("LDX_ATTN_PIPE_MINWG", "1", 1);
     std::mt19937 rng(1234);
     std::normal_distribution<float> nd(0.f, 1.f);
-    const int only = argc > 3 ? atoi(argv[3]) : -1;      // >= 0: skip the parity part and time only that variant (PMC runs)
+    const int only = argc > 3 ? atoi(argv[3]) : -1;
+    const int DD = argc > 4 ? atoi(argv[4]) : 40;      // >= 0: skip the parity part and time only that variant (PMC runs)
     for (int test = 0; test < (only >= 0 ? 0 : 3); ++test) {
-        Prob p; p.B = 1; p.H = 2; p.D = 40; p.N = test == 0 ? 512 : 1024; p.ld = 3 * p.H * p.D;
+        Prob p; p.B = 1; p.H = 2; p.D = DD; p.N = test == 0 ? 512 : 1024; p.ld = 3 * p.H * p.D;
         const int C = p.H * p.D;
         p.qkv.resize((size_t)p.B * p.N * p.ld);
         const float amp = test == 2 ? 4.0f : 1.5f;
@@ -78,17 +80,16 @@ int main(int argc, char** argv) {
             for (int i = 0; i < p.N; i += 3)
                 for (int h = 0; h < p.H; ++h) for (int d = 0; d < p.D; ++d) p.qkv[(size_t)i * p.ld + h * p.D + d] = f2bf((d % 3 == 0 ? 2.0f : -1.5f) + nd(rng) * 0.3f);
         }
-        const float scale = (test == 2) ? 1.0f / 1.44269504088896340736f : 1.0f / std::sqrt(40.0f);      // test 2: the engine's calling convention (c = 1)
+        const float scale = (test == 2) ? 1.0f / 1.44269504088896340736f * (DD == 40 ? 1.f : 0.56f) : 1.0f / std::sqrt((float)DD);      // test 2: the engine's calling convention (c = 1)
         std::vector<double> ref; reference(p, scale, ref);
         void *dq, *dout; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout, (size_t)p.B * p.N * C * 2));
         CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
         printf("test %d: B%d H%d N%d D%d scale %.4f\n", test, p.B, p.H, p.N, p.D, scale);
         struct { const char* tag; const char* pipe; const char* thr; } cfg[] = {
-            {"attn32 (LDX_ATTN_PIPE=0)", "0", nullptr}, {"pipe 4w, default threshold", "1", nullptr},
-            {"pipe 4w, THR=0", "1", "0"}, {"pipe 4w, THR=3", "1", "3"},
-            {"pipe 8w, default threshold", "2", nullptr}, {"pipe 8w, THR=0", "2", "0"}, {"pipe 8w, THR=3", "2", "3"}};
+            {"attn32* (pipelined kernels off)", "0", nullptr}, {"pipe, default threshold", "1", nullptr},
+            {"pipe, THR=0", "1", "0"}, {"pipe, THR=3", "1", "3"}, {"pipe, THR=-1000", "1", "-1000"}};
         for (auto& c : cfg) {
-            setenv("LDX_ATTN_PIPE", c.pipe, 1);
+            setenv("LDX_ATTN_PIPE", c.pipe, 1); setenv("LDX_ATTN_PIPE128", c.pipe, 1);
             if (c.thr) setenv("LDX_ATTN_PIPE_THR", c.thr, 1); else unsetenv("LDX_ATTN_PIPE_THR");
             CK(hipMemset(dout, 0xff, (size_t)p.B * p.N * C * 2));
             run(p, scale, dq, dout, st); CK(hipStreamSynchronize(st));
@@ -101,34 +102,32 @@ int main(int argc, char** argv) {
     }
     // ---- timing
     {
-        Prob p; p.B = 2; p.H = 8; p.D = 40; p.N = NBIG; p.ld = 3 * p.H * p.D;
+        Prob p; p.B = DD == 40 ? 2 : 1; p.H = DD == 40 ? 8 : 24; p.D = DD; p.N = NBIG; p.ld = 3 * p.H * p.D;
         const int C = p.H * p.D;
         p.qkv.resize((size_t)p.B * p.N * p.ld);
         for (auto& x : p.qkv) x = f2bf(nd(rng));
-        void *dq, *dout0, *dout1, *dout2; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout0, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout1, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout2, (size_t)p.B * p.N * C * 2));
+        void *dq, *dout0, *dout1; CK(hipMalloc(&dq, p.qkv.size() * 2)); CK(hipMalloc(&dout0, (size_t)p.B * p.N * C * 2)); CK(hipMalloc(&dout1, (size_t)p.B * p.N * C * 2));
         CK(hipMemcpy(dq, p.qkv.data(), p.qkv.size() * 2, hipMemcpyHostToDevice));
-        const float scale = 1.0f / 1.44269504088896340736f / std::sqrt(40.0f) * 3.0f;
+        const float scale = 1.0f / 1.44269504088896340736f / std::sqrt((float)DD) * 3.0f;
         hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
         const double flop = 4.0 * p.B * p.H * (double)p.N * p.N * p.D;
         for (int round = 0; round < 3; ++round)
-            for (int which = 0; which < 3; ++which) {
+            for (int which = 0; which < 2; ++which) {
                 if (only >= 0 && which != only) continue;
-                setenv("LDX_ATTN_PIPE", which == 0 ? "0" : (which == 1 ? "1" : "2"), 1);
-                void* o = which == 0 ? dout0 : (which == 1 ? dout1 : dout2);
+                setenv("LDX_ATTN_PIPE", which == 0 ? "0" : "1", 1); setenv("LDX_ATTN_PIPE128", which == 0 ? "0" : "1", 1);
+                void* o = which == 0 ? dout0 : dout1;
                 for (int i = 0; i < 3; ++i) run(p, scale, dq, o, st);
                 CK(hipEventRecord(e0, st));
                 for (int i = 0; i < reps; ++i) run(p, scale, dq, o, st);
                 CK(hipEventRecord(e1, st)); CK(hipEventSynchronize(e1));
                 float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-                printf("timing N%d round %d %-10s %.1f us / launch  %.0f TFLOP/s (%.3f of 2.5 PF)\n", p.N, round, which == 0 ? "attn32*" : (which == 1 ? "pipe-4w" : "pipe-8w"), ms * 1e3 / reps, flop / (ms / reps * 1e-3) * 1e-12, flop / (ms / reps * 1e-3) / 2.5e15);
+                printf("timing D%d N%d round %d %-10s %.1f us / launch  %.0f TFLOP/s (%.3f of 2.5 PF)\n", p.D, p.N, round, which == 0 ? "attn32*" : "pipe", ms * 1e3 / reps, flop / (ms / reps * 1e-3) * 1e-12, flop / (ms / reps * 1e-3) / 2.5e15);
             }
         std::vector<uint16_t> a((size_t)p.B * p.N * C), b(a.size());
         CK(hipMemcpy(a.data(), dout0, a.size() * 2, hipMemcpyDeviceToHost));
-        for (void* d : {dout1, dout2}) {
-            CK(hipMemcpy(b.data(), d, b.size() * 2, hipMemcpyDeviceToHost));
-            double num = 0, den = 0; for (size_t i = 0; i < a.size(); ++i) { const double x = bf2f(a[i]), y = bf2f(b[i]); num += (x - y) * (x - y); den += x * x; }
-            printf("big problem: %s vs attn32* rel-L2 %.3e\n", d == dout1 ? "pipe-4w" : "pipe-8w", std::sqrt(num / den));
-        }
+        CK(hipMemcpy(b.data(), dout1, b.size() * 2, hipMemcpyDeviceToHost));
+        double num = 0, den = 0; for (size_t i = 0; i < a.size(); ++i) { const double x = bf2f(a[i]), y = bf2f(b[i]); num += (x - y) * (x - y); den += x * x; }
+        printf("big problem: pipe vs attn32* rel-L2 %.3e\n", std::sqrt(num / den));
     }
     return 0;
 }
