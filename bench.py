@@ -392,8 +392,10 @@ def main(argv=None):
         sync = torch.cuda.synchronize
 
     if world > 1:
-        # N ranks build the same 859.5 M synthetic parameters at once: give each its share of the host cores instead of N x all of them
-        torch.set_num_threads(max(1, (os.cpu_count() or 1) // world))
+        # N ranks build the same 859.5 M synthetic parameters at once: each gets the cores of its GPU's NUMA node (its share of them), not N x all
+        import ldx_amd.parallel as par
+        cpus = par.bind_rank_to_numa(local_rank, world) if not stub else list(range(max(1, (os.cpu_count() or 1) // world)))
+        torch.set_num_threads(max(1, len(cpus)))
     import ldx_amd as ldx
     cfg = ldx.UNetConfig.tiny(64, 128) if args.tiny else ldx.UNetConfig.sd15()
     sd = None

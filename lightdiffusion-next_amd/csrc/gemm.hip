@@ -639,13 +639,17 @@ static void launch_gemm_t(const GemmArgs& a0, hipStream_t s) {
 }
 
 bool gemm_sk_fixup(const GemmArgs& a) {
-    // OPT-IN (LDX_SK_FIXUP=1): measured on the SD1.5 1024^2 step, same box, round 4: reduce launches 14.55 / 14.71 ms, in-kernel reduction up to
+    // OPT-IN at build AND run time (-DLDX_SK_FIXUP_BUILD, LDX_SK_FIXUP=1): measured on the SD1.5 1024^2 step, same box, round 4: reduce launches 14.55 / 14.71 ms, in-kernel reduction up to
     // S = 2: 14.73 (neutral), up to S = 3 / 4: 14.69 / 14.84 (+0.13 ms) — the last arriver's S serial slab reads sit in the tail of the launch,
     // while the reduce kernel spreads the same bytes over the whole chip (and also emits the GroupNorm partials).
+#ifndef LDX_SK_FIXUP_BUILD
+    return false;      // the in-kernel path is not compiled in (gemm_common.h): it costs every instantiation registers
+#else
     static const bool off = !(getenv("LDX_SK_FIXUP") && atoi(getenv("LDX_SK_FIXUP")) != 0);
     static const int max_s = getenv("LDX_SK_FIXUP_MAX") ? atoi(getenv("LDX_SK_FIXUP_MAX")) : SK_FIXUP_MAX_S;
     if (off || !a.sk_count || !a.ws || a.splitk < 2 || a.splitk > max_s || a.geglu) return false;
     return (long)((a.M + 63) / 64) * ((a.N + 31) / 32) <= SK_COUNTERS;      // an upper bound on the tile count of any tile shape
+#endif
 }
 
 // Planner query (GemmArgs::gn_partial): which tile will launch_gemm_mode pick for `a`, and can that tile's epilogue produce the consumer

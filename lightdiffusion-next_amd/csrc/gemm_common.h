@@ -72,8 +72,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
     //     ticket; the workgroup that draws S - 1 resets the counter and reads ALL S slabs (its own too: the sum does not depend on who is last)
     //     in split order with sc1 loads, 16 bytes per lane, MI * NJ loads in flight per slab.
     // Placement-independent: nothing assumes which XCD a split runs on.
+    // Only built with -DLDX_SK_FIXUP_BUILD: compiled into every instantiation the path cost the register-staged kernels 16-73 VGPRs (128 x 128: 176 -> 249,
+    // 128 x 160: 124-132 bytes of scratch, 64 x 64: five -> four waves per SIMD) and the VAE decode 3 ms (14.8 -> 17.8), for a scheme that measured slower.
     if (S > 1) {
-        if (p.sk_count == nullptr) {
+#ifdef LDX_SK_FIXUP_BUILD
+        if (p.sk_count == nullptr)
+#endif
+        {
             float* __restrict__ ws = p.ws + (size_t)split * p.M * p.N;
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
@@ -88,6 +93,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
             }
             return;
         }
+#ifdef LDX_SK_FIXUP_BUILD
         extern __shared__ __attribute__((aligned(16))) char smem_ep[];
         const int tile = (m0 / BM) * ((p.N + BN - 1) / BN) + n0 / BN;
         constexpr int SLAB = BM * BN;                                   // floats
@@ -128,6 +134,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
 #pragma unroll
                 for (int j = 0; j < NJ; ++j) acc[i][j] += t[i][j];
         }
+#endif
     }
     // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
     if (p.C8) {

@@ -155,3 +155,69 @@ def unpad_gathered(recv: torch.Tensor, total: int, world: int) -> torch.Tensor:
         lo, hi = shard_bounds(total, r, world)
         out.append(recv[r * per: r * per + (hi - lo)])
     return torch.cat(out, dim=0)
+
+
+# ---- rank -> GPU -> NUMA-node CPU affinity (round 4).  Eight ranks that each synthesise / convert 860 M parameters on "all" host threads serialise on
+# one socket; each rank gets the cores of its GPU's NUMA node (sysfs), split evenly among the ranks that share the node.
+
+def parse_cpulist(text: str):
+    """'0-3,8,10-11' -> [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/node*/cpulist)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        if "-" in part:
+            a, b = part.split("-")
+            out.extend(range(int(a), int(b) + 1))
+        else:
+            out.append(int(part))
+    return sorted(set(out))
+
+
+def plan_rank_cpus(allowed, node_of_rank, node_cpus, local_rank: int):
+    """CPUs for `local_rank`.  allowed: CPUs this process may use; node_of_rank: NUMA node per local rank (-1 / None = unknown);
+    node_cpus: {node: [cpus]}.  Ranks with a known node share that node's allowed CPUs evenly (in rank order); ranks without one share
+    `allowed` evenly over all local ranks.  Never returns an empty list."""
+    allowed = sorted(set(allowed))
+    world = len(node_of_rank)
+    node = node_of_rank[local_rank]
+    pool = sorted(set(node_cpus.get(node, [])) & set(allowed)) if node is not None and node >= 0 else []
+    if pool:
+        peers = [r for r in range(world) if node_of_rank[r] == node]
+    else:
+        pool, peers = allowed, list(range(world))
+    i, n = peers.index(local_rank), len(peers)
+    lo, hi = i * len(pool) // n, (i + 1) * len(pool) // n
+    return pool[lo:hi] if hi > lo else [pool[i % len(pool)]]
+
+
+def gpu_numa_node(device_index: int) -> int:
+    """NUMA node of a visible GPU from sysfs (PCI address from the device properties); -1 when the platform does not say."""
+    try:
+        pr = torch.cuda.get_device_properties(device_index)
+        bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
+        with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
+            return int(f.read().strip())
+    except Exception:
+        return -1
+
+
+def bind_rank_to_numa(local_rank: int, local_world: int):
+    """Restrict this process to its share of the cores next to its GPU; returns the CPU list (also the torch thread count to use)."""
+    import glob
+    import os
+    allowed = sorted(os.sched_getaffinity(0))
+    nodes = {}
+    for d in glob.glob("/sys/devices/system/node/node[0-9]*"):
+        try:
+            with open(os.path.join(d, "cpulist")) as f:
+                nodes[int(os.path.basename(d)[4:])] = parse_cpulist(f.read())
+        except Exception:
+            pass
+    node_of_rank = [gpu_numa_node(r) for r in range(local_world)]
+    cpus = plan_rank_cpus(allowed, node_of_rank, nodes, local_rank)
+    try:
+        os.sched_setaffinity(0, cpus)
+    except Exception:
+        pass
+    return cpus

@@ -95,6 +95,12 @@ if __name__ == "__main__":
         gemm(8192, 8192, 8192, reps=2)
     if what == "attn1":
         attn(reps=3)
+    if what == "attn128":      # one Flux joint-attention launch
+        attn(B=1, H=24, N=4352, D=128, reps=3)
+    if what == "gemm640":      # a plain mid-size projection (SD1.5 64^2 level)
+        gemm(8192, 640, 640, reps=3)
+    if what == "deep1":        # a weight-streaming split-K conv of the 16^2 level (M = 512)
+        conv(H=16, Cin=1280, Cout=1280, reps=3)
     if what in ("attn", "all"):
         attn(); attn(N=4096, D=80); attn(N=1024, D=160); attn(N=16384, M=77)
     if what in ("gemm", "all"):
