@@ -490,6 +490,31 @@ def main(argv=None):
         except Exception as e:      # noqa: BLE001 — reported in the line
             rccl_direct = {"ok": False, "error": repr(e)[:300]}
 
+    # config 3, end to end: every rank decodes ITS OWN shard of the final latents (the decode is sharded like the sampling; gathering u8 RGB would move
+    # 3 MiB per image against 64 KiB per latent, so the images stay with the rank that made them and only the latents are gathered).  After the timed
+    # regions, guarded like the direct RCCL check: reported next to the headline, never part of it.
+    e2e3 = None
+    if args.config == 3 and not stub and not args.tiny:
+        try:
+            vcfg = ldx.VAEConfig()
+            vae = ldx.VAEDecoderEngine(vcfg, ldx.weights.synth_state_dict(ldx.weights.vae_decoder_state_dict_spec(vcfg), seed=1, dtype=torch.float32), device=local_rank, dtype="bf16")
+            mine_lat = gathered[lo_:hi_].contiguous()
+            vae.decode(mine_lat[:1]); sync()                                        # plan + warm
+            fence(); tv0 = time.perf_counter()
+            for i in range(pb):
+                img = vae.decode(mine_lat[i:i + 1])
+            sync(); tv1 = time.perf_counter()
+            assert torch.isfinite(img.float()).all()
+            dec_ms = 1e3 * (tv1 - tv0)
+            if dist:
+                tmx = torch.tensor([dec_ms], device=dev, dtype=torch.float64)
+                dist.all_reduce(tmx, op=dist.ReduceOp.MAX)
+                dec_ms = float(tmx.item())
+            e2e3 = {"ok": True, "vae_decodes_per_rank": pb, "vae_decode_ms_per_rank_max": round(dec_ms, 2), "where": "each rank decodes its own shard after the latent gather"}
+            del vae
+        except Exception as e:      # noqa: BLE001 — reported in the line
+            e2e3 = {"ok": False, "error": repr(e)[:300]}
+
     # MAX over ranks per region; per-rank medians for the report
     per_rank_ms = [1000.0 * statistics.median(regions) / args.steps]
     if dist:
@@ -623,7 +648,7 @@ def main(argv=None):
                        "region_ms_per_step": [round(1000.0 * r / args.steps, 3) for r in regions_max],
                        "per_rank_ms_per_step": [round(v, 3) for v in per_rank_ms],
                        "allgather_ms": round(1000.0 * statistics.median(gathers_max), 3),
-                       "allgather_bytes": int(gathered.numel() * 4), "rccl_direct": rccl_direct,
+                       "allgather_bytes": int(gathered.numel() * 4), "rccl_direct": rccl_direct, "config3_e2e": e2e3,
                        "backend": (dist.get_backend() if dist else None), "rccl_ranks": (dist.get_world_size() if dist else 1),
                        "latents_sha256_16": hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]},
             "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,

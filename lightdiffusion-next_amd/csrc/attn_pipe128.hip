@@ -1,18 +1,21 @@
 // Software-pipelined flash attention for D = 128 (Flux DiT joint attention, 57 launches of B1 H24 N4352 per forward) — round 4.
 // Reference call site: Flux.py:298-348 / 389-418 (attention() -> F.scaled_dot_product_attention on the RoPE'd q, k), no mask.
 //
-// The schedule of attn_pipe.hip (one wave per SIMD, 64 queries per wave, 64-key slots; in slot t the matrix pipe runs QK^T(t+1) and PV(t-1) while the
-// VALU turns S(t) into P(t)) carried to a head dim where the matrix work per slot is 64 MFMAs instead of 28.  What differs from D = 40:
-//   * no spare contraction slots (128 = 8 x 16): S is the raw score and the softmax piece does exp2(fma(s, c, -m_ref)) itself; the denominator is
-//     summed on the VALU from the ROUNDED P (v_dot2_f32_{bf16,f16} with a pair of ones: one instruction per two keys, and the same rounded values
-//     the PV MFMAs see) instead of a fifth d tile; the reference maximum is still lazy and integer-valued (raised by dl >= 0 at the end of a slot,
-//     BEFORE any exponential of block t + 1, only when some score of that block exceeds 2^THR: O, l and the packed P(t) are scaled by 2^-dl, exactly).
-//   * 64 MFMA gaps per slot leave room to read every K / V^T fragment just in time (three fragments ahead of its two MFMAs, rotating through four
-//     registers sets) instead of holding a block's fragments: S(t), S(t+1), P(t-1), P(t) (192 VGPRs) + O (128 AGPRs) + Q (64 AGPRs) are what lives.
-//   * the softmax is issued as 64 half-pieces (one exponential each), ONE per gap: a gap then costs about as much issue time as its MFMA runs.
-//   * K / V rings are three deep: what slot t stores (K(t+3), V(t+1)) is first read in slot t + 2 (the last gaps of slot t + 1 for K), so the one
-//     barrier per slot never sits between a store and the read that needs it.  One staging register set: chunk i is stored and its register
-//     reloaded with the next tile's chunk in the same gap (a full slot of latency cover per load).
+// The schedule of attn_pipe.hip (one wave per SIMD, 64 queries per wave; the matrix pipe runs QK^T of the NEXT keys and PV of the PREVIOUS ones while
+// the VALU turns the current scores into P) carried to a head dim where the matrix work per 64 keys is 64 MFMAs instead of 28.  What differs from D = 40:
+//   * the pipeline advances in HALF-slots of 32 keys (one 32-key tile x two q tiles): S and P buffers are 32 + 32 and 16 + 16 registers instead of twice
+//     that (as 64-key slots the kernel needed 562 registers and spilled); per half-slot 16 QK^T MFMAs (8 k-steps x 2 q tiles) and 16 PV MFMAs
+//     (2 key steps x 4 d tiles x 2 q tiles), one barrier per 64-key block.
+//   * no spare contraction slots (128 = 8 x 16): S is the raw score and the softmax half-piece does exp2(fma(s, c, -m_ref)) itself, in fp32; the
+//     denominator is summed on the VALU from the ROUNDED P (v_dot2_f32_{bf16,f16} with a pair of ones: one instruction per two keys, and the same rounded
+//     values the PV MFMAs see) instead of a fifth d tile; the reference maximum is still lazy and integer-valued (raised by dl >= 0 at the end of a
+//     half-slot, BEFORE any exponential of the next half, only when some score of it exceeds 2^THR: O, l and the packed P are scaled by 2^-dl, exactly).
+//   * every K / V^T fragment is read just in time (three fragments ahead of its two MFMAs, rotating through four register sets) instead of holding a
+//     block's fragments: what lives is S (64 VGPRs), P (32), O (128 AGPRs) and Q (64 AGPRs).
+//   * the softmax is issued as half-pieces (one exponential each), ONE per MFMA gap.
+//   * K / V rings are three deep: what block t stores (K(t+2), V(t+1)) is first read in block t + 1, behind that block's barrier, and its ring slots were
+//     last read in block t - 1.  One staging register set: chunk i is stored and its register reloaded with the next tile's chunk in the same gap
+//     (a full block of latency cover per load).
 // Output: 16-bit O, or the MX fp8 bytes + one scale dword per (row, head) of attn32g's D = 128 epilogue (AttnArgs::O8, Flux fp8 mode).
 // Shapes taken: D = 128, Nq % 256 == 0, Mk % 128 == 0, Mk >= 256, no mask / bias; everything else stays on attn32g (attention.hip).
 #include <stdlib.h>
