@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
                 constexpr int qt = decltype(QT)::value;
                 const float mnew = fminf(mref[qt] + fmaxf(ceilf(qt ? bm1 : bm0), 0.f), 60000.f);
                 const float dl = mnew - mref[qt];                                // integer >= 0
-                { const float al = __builtin_amdgcn_exp2f(-dl); o[qt][0] = o[qt][0] * al; o[qt][1] = o[qt][1] * al; asm volatile("" : "+a"(o[qt][0])); asm volatile("" : "+a"(o[qt][1])); }
+                { const float al = __builtin_amdgcn_exp2f(-dl); ap_scale_acc8<0>(o[qt][0], al); ap_scale_acc8<8>(o[qt][0], al); ap_scale_acc8<0>(o[qt][1], al); ap_scale_acc8<8>(o[qt][1], al); }
                 const unsigned de = (unsigned)fminf(dl, (float)ApT<T>::maxdl) << ApT<T>::expsh;
                 const unsigned de2 = de | (de << 16);
 #pragma unroll

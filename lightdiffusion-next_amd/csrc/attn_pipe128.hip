@@ -47,21 +47,6 @@ template <typename T> __device__ __forceinline__ void ap128_rowsum(float& l, int
     else asm("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(l) : "v"(r), "s"(ones));
 }
 
-// O *= al for eight registers of an accumulator tile, as asm on the AGPRs themselves: written as o = o * al the rare path gives hipcc a VGPR use of O,
-// and it then carries parts of O in VGPRs around the loop (24 v_accvgpr copies each way per block on the COMMON path)
-template <int R0> __device__ __forceinline__ void ap128_scale_acc8(f32x16& t, float al) {
-    float tmp;
-    asm volatile("v_accvgpr_read_b32 %8, %0\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %0, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %1\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %1, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %2\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %2, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %3\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %3, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %4\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %4, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %5\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %5, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %6\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %6, %8\n\t"
-                 "v_accvgpr_read_b32 %8, %7\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %7, %8\n\ts_nop 4"
-                 : "+a"(t[R0]), "+a"(t[R0 + 1]), "+a"(t[R0 + 2]), "+a"(t[R0 + 3]), "+a"(t[R0 + 4]), "+a"(t[R0 + 5]), "+a"(t[R0 + 6]), "+a"(t[R0 + 7]), "=&v"(tmp) : "v"(al));
-}
-
 // ABL: timing ablations (wrong results; LDX_ATTN_PIPE_ABL with -DLDX_ATTN_ABLATE): 1 no s_barrier, 2 no maximum, 4 no MFMAs, 8 no staging, 16 no fragment reads, 32 no softmax
 template <typename T, int ABL>
 __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, const float thr) {
@@ -278,7 +263,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
                 const float dl = fminf(fmaxf(ceilf(qt ? bm1 : bm0), 0.f), 1e30f);      // integer >= 0
                 const float al = __builtin_amdgcn_exp2f(-dl);
 #pragma unroll
-                for (int dt = 0; dt < 4; ++dt) { ap128_scale_acc8<0>(o[qt][dt], al); ap128_scale_acc8<8>(o[qt][dt], al); }
+                for (int dt = 0; dt < 4; ++dt) { ap_scale_acc8<0>(o[qt][dt], al); ap_scale_acc8<8>(o[qt][dt], al); }
                 lsum[qt] *= al;
                 const unsigned de = (unsigned)fminf(dl, (float)ApT<T>::maxdl) << ApT<T>::expsh;
                 const unsigned de2 = de | (de << 16);

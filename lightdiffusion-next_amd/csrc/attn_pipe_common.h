@@ -62,4 +62,19 @@ template <int LO, int... I> constexpr auto ap_range_impl(std::integer_sequence<i
 template <int LO, int HI> constexpr auto ap_range() { return ap_range_impl<LO>(std::make_integer_sequence<int, HI - LO>{}); }
 template <int N> using ap_ic = std::integral_constant<int, N>;
 
+// O *= al for eight registers of an accumulator tile, as asm on the AGPRs themselves: written as o = o * al the rare path gives hipcc a VGPR use of O,
+// and it then carries parts of O in VGPRs around the loop (24 v_accvgpr copies each way per block on the COMMON path)
+template <int R0> __device__ __forceinline__ void ap_scale_acc8(f32x16& t, float al) {
+    float tmp;
+    asm volatile("v_accvgpr_read_b32 %8, %0\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %0, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %1\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %1, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %2\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %2, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %3\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %3, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %4\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %4, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %5\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %5, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %6\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %6, %8\n\t"
+                 "v_accvgpr_read_b32 %8, %7\n\tv_mul_f32 %8, %8, %9\n\tv_accvgpr_write_b32 %7, %8\n\ts_nop 4"
+                 : "+a"(t[R0]), "+a"(t[R0 + 1]), "+a"(t[R0 + 2]), "+a"(t[R0 + 3]), "+a"(t[R0 + 4]), "+a"(t[R0 + 5]), "+a"(t[R0 + 6]), "+a"(t[R0 + 7]), "=&v"(tmp) : "v"(al));
+}
+
 }  // namespace ldx

@@ -551,6 +551,7 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
 
 template <typename T, int MODE, int BM, int BN, int WM = 2, bool F8 = false, bool LNF = false>
 static void launch_gemm_inst(const GemmArgs& a, int S, hipStream_t s) {
+    gemm_gn_tile_check(a, BM, BN, S);
     const int tiles = ((a.M + BM - 1) / BM) * ((a.N + BN - 1) / BN) * S;
     const size_t lds = 2 * stage_bytes<BM, BN>();
     static DevOnce once;
@@ -650,6 +651,15 @@ bool gemm_sk_fixup(const GemmArgs& a) {
     if (off || !a.sk_count || !a.ws || a.splitk < 2 || a.splitk > max_s || a.geglu) return false;
     return (long)((a.M + 63) / 64) * ((a.N + 31) / 32) <= SK_COUNTERS;      // an upper bound on the tile count of any tile shape
 #endif
+}
+
+void gemm_gn_tile_check(const GemmArgs& a, int BM, int BN, int S) {
+    if (!a.gn_partial || S > 1 || a.gn_cpg <= 0) return;       // split-K: the reduce launch owns the statistics and checks its own geometry
+    if (a.gn_hw % BM || a.gn_nchunk != a.gn_hw / BM || BN % a.gn_cpg || BN > 160) {
+        fprintf(stderr, "ldx: GroupNorm-statistics geometry mismatch: planned for %d chunks of an image of %d rows, %d channels per group; launching %d x %d tiles\n",
+                a.gn_nchunk, a.gn_hw, a.gn_cpg, BM, BN);
+        abort();
+    }
 }
 
 // Planner query (GemmArgs::gn_partial): which tile will launch_gemm_mode pick for `a`, and can that tile's epilogue produce the consumer

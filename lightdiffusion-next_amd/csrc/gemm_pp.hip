@@ -28,6 +28,7 @@ static void launch_pp_t(const GemmArgs& a, int bn, bool lnf, int S, hipStream_t 
     }
 }
 void launch_gemm_pp(const GemmArgs& a, int bn, bool lnf, int S, DType dt, hipStream_t s) {
+    gemm_gn_tile_check(a, 256, (lnf || a.geglu) && bn != 160 ? 128 : bn, S);
     if (dt == DT_BF16) launch_pp_t<__bf16>(a, bn, lnf, S, s); else launch_pp_t<_Float16>(a, bn, lnf, S, s);
 }
 

@@ -83,6 +83,9 @@ struct GemmArgs {
 };
 // Can launch_gemm(a) produce GroupNorm statistics for a consumer GroupNorm(G groups) over [B][HW][a.N]?  If yes, returns the number of
 // tile rows per batch image (the consumer's chunk count) and fills a.gn_* except gn_partial; 0 = not fusable (the GroupNorm runs its own pass).
+// Launch-side guard for GemmArgs::gn_partial without split-K: the tile the launcher instantiates must be the one gemm_gn_fuse() planned the partial
+// layout for (chunk = one BM-row tile of an image, whole groups inside a BN-column tile); aborts otherwise instead of feeding the GroupNorm stale rows.
+void gemm_gn_tile_check(const GemmArgs& a, int BM, int BN, int S);
 int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks);
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s);
 // two independent plain GEMMs (mode 0, no split-K / GEGLU, both 16-bit or both MX) as one launch of 128x128 tiles
@@ -130,6 +133,7 @@ struct AttnArgs {
     float* knorm_ws;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+
 // Software-pipelined D = 40 kernel (attn_pipe.hip, round 4): attn_pipe_ok() says whether it takes the shape (D = 40, Nq % 256 == 0, Mk % 128 == 0,
 // Mk >= 256, no mask / bias); thr_override = NaN keeps the type's rescale threshold (tests force the rare path with small values).
 bool attn_pipe_ok(const AttnArgs& a);
