@@ -386,6 +386,13 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
 // builtins): 863 us against 835 with QK^T / PV as phases, 963 us with the two MFMA kinds interleaved into four accumulator chains per wave — the two
 // waves of a SIMD share its VALU issue port and matrix pipe, and what one gains the other loses.
 
+// max ||k|| per 64-key block into a.knorm_ws (B * H * ceil(Mk / 64) floats): shared with attn_pipe128.hip
+void launch_attn_knorm(const AttnArgs& a, DType dt, hipStream_t s) {
+    const long waves = (long)a.B * a.H * ((a.Mk + 63) / 64);
+    if (dt == DT_BF16) hipLaunchKernelGGL((attn_knorm_kernel<__bf16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((attn_knorm_kernel<_Float16>), dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, s, a);
+}
+
 bool attn_pipe_ok(const AttnArgs& a) {
     return a.D == 40 && !a.causal && !a.bias && !a.O8 && a.Nq % 256 == 0 && a.Mk % 128 == 0 && a.Mk >= 256 &&
            a.ldq % 8 == 0 && a.ldk % 8 == 0 && a.ldv % 8 == 0 && a.ldo % 4 == 0;

@@ -42,13 +42,27 @@ template <typename T> __device__ __forceinline__ void ap128_half_b(float sb, flo
 __device__ __forceinline__ void ap128_exp1(float s, float c, float nm, float& x) {
     asm("v_fma_f32 %0, %1, %2, %3\n\tv_exp_f32 %0, %0" : "=&v"(x) : "v"(s), "s"(c), "v"(nm));
 }
+// QK^T MFMAs of this kernel: K fragment (A operand) in arch VGPRs, Q fragment in AGPRs, S in arch VGPRs.  (With the K fragments in AGPRs as in attn_pipe.hip
+// hipcc overlapped them with an O tile and saved / restored that tile around every block: 16 + 16 v_accvgpr copies.)
+template <typename T> __device__ __forceinline__ void ap128_sacc0(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile(AP_BF16 " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+    else asm volatile(AP_F16 " %0, %1, %2, 0" : "=&v"(d) : "v"(a), "a"(b));
+}
+template <typename T> __device__ __forceinline__ void ap128_sacc(f32x16& d, ap_i32x4 a, ap_i32x4 b) {
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile(AP_BF16 " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+    else asm volatile(AP_F16 " %0, %1, %2, %0" : "+v"(d) : "v"(a), "a"(b));
+}
+// The dot product is opaque to hipcc's hazard recogniser inside an asm: it pads ONE wait state between this and a plain VALU read of l, and that is not
+// enough on gfx950 — in the KB variant the copy of l for the loop exit sat right behind the last of these and read the OLD value: the last dword of P of
+// the last half-slot was missing from the denominator of every query of q tile 1 (found as a probability mass of 0.12 on key 507 of 512).  Callers
+// put an s_nop run behind the last row sum.
 template <typename T> __device__ __forceinline__ void ap128_rowsum(float& l, int r, int ones) {
-    if constexpr (std::is_same<T, __bf16>::value) asm("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(l) : "v"(r), "s"(ones));
-    else asm("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(l) : "v"(r), "s"(ones));
+    if constexpr (std::is_same<T, __bf16>::value) asm volatile("v_dot2_f32_bf16 %0, %1, %2, %0" : "+v"(l) : "v"(r), "s"(ones));
+    else asm volatile("v_dot2_f32_f16 %0, %1, %2, %0" : "+v"(l) : "v"(r), "s"(ones));
 }
 
 // ABL: timing ablations (wrong results; LDX_ATTN_PIPE_ABL with -DLDX_ATTN_ABLATE): 1 no s_barrier, 2 no maximum, 4 no MFMAs, 8 no staging, 16 no fragment reads, 32 no softmax
-template <typename T, int ABL>
+template <typename T, int ABL, bool KB>
 __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, const float thr) {
     constexpr int D = 128, KVB = 64, KROWB = 272, VROWB = 320;      // row strides: conflict-free b128 (K) and transposing b64 (V) fragment reads
     constexpr int KBYTES = KVB * KROWB, VBYTES = KVB * VROWB, VBASE = 3 * KBYTES;
@@ -74,6 +88,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
 
     // Q fragments (B operand of QK^T): lane holds q = l31, d = 16 ks + 8 h2 .. +7 (raw: the scale is applied with the reference in the softmax fma)
     ap_i32x4 qf[2][8];
+    float qnc[2] = {0.f, 0.f};                       // KB: ||q c||_2 of the lane's queries (x 1.002)
     {
         uint4 qu[2][8];                              // all sixteen loads in flight before the first is pinned (an asm use waits for its load)
 #pragma unroll
@@ -88,7 +103,22 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
                 asm volatile("" : "+a"(w));          // AGPR home (see attn_pipe.hip)
                 qf[qt][ks] = w;
             }
+        if constexpr (KB) {
+#pragma unroll
+            for (int qt = 0; qt < 2; ++qt) {
+                float ss = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    const V8 v = as_v8<T>(qu[qt][ks]);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss = fmaf((float)v[e], (float)v[e], ss);
+                }
+                auto sw = __builtin_amdgcn_permlane32_swap(__float_as_uint(ss), __float_as_uint(ss), false, false);
+                qnc[qt] = sqrtf(__uint_as_float(sw[0]) + __uint_as_float(sw[1])) * 1.002f * c;      // ||q|| c (rounded up): s c <= ||q|| c ||k||
+            }
+        }
     }
+    const __amdgpu_buffer_rsrc_t rN = __builtin_amdgcn_make_buffer_rsrc((void*)(KB ? p.knorm_ws + (long)hb * nblk : nullptr), 0, KB ? nblk * 4 : 0, 0x00020000);
 
     // ---- staging: a 64 x 256 B tile is 1024 16-byte chunks = four per thread (rows srow + 16 i, chunk sch); chunks 0-3 K, 4-7 V
     const int srow = tid >> 4, sch = tid & 15;
@@ -146,8 +176,8 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
     // (16-key step (j >> 3) of the half, d tile (j >> 1) & 3), q tile j & 1
     auto qk1 = [&](auto I, f32x16 (&s)[2]) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value, ks = i >> 1, qt = i & 1;
-        if constexpr (ks == 0) ap_sacc0<T>(s[qt], ap_bits(kfr[0]), qf[qt][0]);
-        else ap_sacc<T>(s[qt], ap_bits(kfr[ks & 3]), qf[qt][ks]);
+        if constexpr (ks == 0) ap128_sacc0<T>(s[qt], ap_bits(kfr[0]), qf[qt][0]);
+        else ap128_sacc<T>(s[qt], ap_bits(kfr[ks & 3]), qf[qt][ks]);
     };
     auto pv1 = [&](auto J, ap_i32x4 (&pf)[2][2]) __attribute__((always_inline)) {
         constexpr int j = decltype(J)::value, f = j >> 1, st = f >> 2, dt = f & 3, qt = j & 1;
@@ -208,11 +238,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
             m = fmaxf(__uint_as_float(sw[0]), __uint_as_float(sw[1]));
             nm[qt] = -fminf(fmaxf(ceilf(m * c), -1e30f), 1e30f);
         });
-        ap_for(ap_range<0, 3>(), [&](auto F) __attribute__((always_inline)) {      // pinned to AGPRs: the loop-carried kfr[0..2] then have one register class on both edges
-            ap_i32x4 w = ap_bits(*(const uint4*)(kp + 32 * KROWB + decltype(F)::value * 32));
-            asm volatile("" : "+a"(w));
-            kfr[decltype(F)::value] = __builtin_bit_cast(V8, w);
-        });
+        ap_for(ap_range<0, 3>(), [&](auto F) __attribute__((always_inline)) { kfr[decltype(F)::value] = as_v8<T>(*(const uint4*)(kp + 32 * KROWB + decltype(F)::value * 32)); });
     }
 
     // ---- block t (ring indices r0 = t % 3, r1 = (t + 1) % 3, r2 = (t + 2) % 3), two half-slots u = 2 t + PAR of 32 MFMA gaps each:
@@ -227,7 +253,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
         const char* kp = smem + (PAR ? r1 : r0) * KBYTES + (1 - PAR) * 32 * KROWB + lane_k;      // this half-slot's keys
         const char* kpn = smem + r1 * KBYTES + PAR * 32 * KROWB + lane_k;                         // the next half-slot's: fragments 0..2 for its first MFMAs
         const char* vp = smem + (PAR ? r0 : r2) * VBYTES + (1 - PAR) * 32 * VROWB + lane_v;
-        float bm0 = 0.f, bm1 = 0.f;
+        float bm0 = 0.f, bm1 = 0.f, kn = 0.f;
         auto gap = [&](auto G) __attribute__((always_inline)) {
             constexpr int g = decltype(G)::value;
             if constexpr (g == 0 && PAR == 0) {
@@ -241,10 +267,15 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
             if constexpr ((g & 1) == 0 && g >= 10 && g <= 24 && !(ABL & 16)) vread(ap_ic<(g - 10) / 2>{}, vp);
             if constexpr ((g == 26 || g == 28 || g == 30) && !(ABL & 16)) kfr[(g - 26) / 2] = as_v8<T>(*(const uint4*)(kpn + ((g - 26) / 2) * 32));
             if constexpr ((g & 7) == 5 && !(ABL & 8)) { lstore1(ap_ic<4 * PAR + (g >> 3)>{}, r2, r1); gload1(ap_ic<4 * PAR + (g >> 3)>{}, t + 3, t + 2); }
+            if constexpr (KB && g == 3) kn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rN, 0, min(t + PAR, nblk - 1) * 4, 0));      // max ||k|| of the block sn belongs to
             if constexpr (!(ABL & 32)) half(G, sc, pc);
-            if constexpr ((g == 21 || g == 23 || g == 25 || g == 27) && !(ABL & 2)) maxblk(ap_ic<(g - 21) / 2>{}, sn);      // its last MFMA issued in gap 15
-            if constexpr (g == 29 && !(ABL & 2)) bm0 = bmax(0);
-            if constexpr (g == 31 && !(ABL & 2)) bm1 = bmax(1);
+            if constexpr (!KB) {
+                if constexpr ((g == 21 || g == 23 || g == 25 || g == 27) && !(ABL & 2)) maxblk(ap_ic<(g - 21) / 2>{}, sn);      // its last MFMA issued in gap 15
+                if constexpr (g == 29 && !(ABL & 2)) bm0 = bmax(0);
+                if constexpr (g == 31 && !(ABL & 2)) bm1 = bmax(1);
+            } else if constexpr (g == 29) {          // bound on s c - m_ref from the norms (Cauchy-Schwarz), no look at the scores
+                bm0 = fmaf(qnc[0], kn, nm[0]); bm1 = fmaf(qnc[1], kn, nm[1]);
+            }
             __builtin_amdgcn_sched_barrier(0);
         };
         __builtin_amdgcn_sched_barrier(0);
@@ -255,8 +286,9 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
             pc[j >> 3][(j >> 2) & 1][j & 3] = r;
             ap128_rowsum<T>(lsum[j >> 3], r, ones);
         });
+        asm volatile("s_nop 7" ::: "memory");          // the dot2 results land before anything reads lsum (see ap128_rowsum)
         // rare path: some query's score in sn exceeds 2^thr over the reference: raise it by the integer dl
-        if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) {
+        auto raise_reference = [&]() __attribute__((always_inline)) {
             asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");      // the PV MFMAs have landed in O
             ap_for(ap_range<0, 2>(), [&](auto QT) __attribute__((always_inline)) {
                 constexpr int qt = decltype(QT)::value;
@@ -273,6 +305,18 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
                     for (int w = 0; w < 4; ++w) asm volatile("v_pk_sub_u16 %0, %0, %1 clamp" : "+v"(pc[qt][st][w]) : "v"(de2));      // this half's P *= 2^-dl (exponent field, saturating at 0)
                 nm[qt] -= dl;
             });
+        };
+        if constexpr (KB) {
+            // ONE branch on the common path: the bound does not prove this half safe for some query of the wave -> the exact maximum (what the other
+            // variant does in every half-slot), and only inside that the threshold test proper (see attn_pipe.hip)
+            if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) {
+                asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+                ap_for(ap_range<0, 4>(), [&](auto M) __attribute__((always_inline)) { maxblk(M, sn); });
+                bm0 = bmax(0); bm1 = bmax(1);
+                if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) raise_reference();
+            }
+        } else {
+            if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) raise_reference();
         }
     };
     int r0 = 0, r1 = 1, r2 = 2;
@@ -355,9 +399,18 @@ bool attn_pipe128_ok(const AttnArgs& a) {
 template <typename T, int ABL = 0>
 static void launch_attn128p(const AttnArgs& a, hipStream_t s, float thr) {
     const size_t lds = 3 * 64 * (272 + 320);
-    static DevOnce once;
-    set_dyn_lds(once, (const void*)attn128p_kernel<T, ABL>, (int)lds);
-    hipLaunchKernelGGL((attn128p_kernel<T, ABL>), dim3((a.Nq / 256) * a.H * a.B), dim3(256), lds, s, a, thr);
+    const dim3 grid((a.Nq / 256) * a.H * a.B);
+    static const bool kb_off = getenv("LDX_ATTN_PIPE_KB") && atoi(getenv("LDX_ATTN_PIPE_KB")) == 0;      // experiment switch: exact maximum on every half-slot
+    if (a.knorm_ws && !kb_off && ABL == 0) {
+        launch_attn_knorm(a, std::is_same<T, __bf16>::value ? DT_BF16 : DT_F16, s);
+        static DevOnce once;
+        set_dyn_lds(once, (const void*)attn128p_kernel<T, ABL, true>, (int)lds);
+        hipLaunchKernelGGL((attn128p_kernel<T, ABL, true>), grid, dim3(256), lds, s, a, thr);
+    } else {
+        static DevOnce once;
+        set_dyn_lds(once, (const void*)attn128p_kernel<T, ABL, false>, (int)lds);
+        hipLaunchKernelGGL((attn128p_kernel<T, ABL, false>), grid, dim3(256), lds, s, a, thr);
+    }
 }
 
 void launch_attn_pipe128(const AttnArgs& a, DType dt, hipStream_t s, float thr_override) {

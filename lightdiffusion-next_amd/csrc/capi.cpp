@@ -358,6 +358,7 @@ int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const vo
     a.O8 = O8; a.ldo8 = ldo8; a.SO = (uint32_t*)SO; a.so_ld = so_ld;
     if (!Q || !K || !V || !O8 || !SO || B <= 0 || H <= 0 || Nq <= 0 || Mk <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo8 % 16 || ldo8 < H * 128 || so_ld < B * Nq) {
         set_error("ldx_op_attention_mx: bad argument"); return LDX_EINVAL; }
+    if (attn_pipe128_ok(a)) a.knorm_ws = op_workspace((size_t)B * H * ((Mk + 63) / 64));
     if (!attention_mx_out_ok(a)) { set_error("ldx_op_attention_mx: needs head dim 128 and at least 16 query blocks of 128 (B * H * ceil(Nq / 128))"); return LDX_EINVAL; }
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention_mx");
@@ -461,7 +462,7 @@ int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void*
                      float scale, int causal, int dtype, void* stream) {
     if (!Q || !K || !V || !O || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160)"); return LDX_EINVAL; }
     AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal, nullptr, 0, 0};
-    if (attn_pipe_ok(a)) a.knorm_ws = op_workspace((size_t)B * H * ((Mk + 63) / 64));      // (shared single-op scratch: one stream per device, include/ldx.h)
+    if (attn_pipe_ok(a) || attn_pipe128_ok(a)) a.knorm_ws = op_workspace((size_t)B * H * ((Mk + 63) / 64));      // (shared single-op scratch: one stream per device, include/ldx.h)
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention");
 }

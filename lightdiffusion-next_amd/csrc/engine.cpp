@@ -659,7 +659,7 @@ void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, in
     AttnArgs& a = o.at;
     a.Q = Q; a.ldq = ldq; a.K = K; a.ldk = ldk; a.V = V; a.ldv = ldv; a.O = ptr(O); a.ldo = O.ld;
     a.B = B; a.H = H; a.Nq = Nq; a.Mk = Mk; a.D = D; a.scale = 1.0f / std::sqrt((float)D); a.causal = 0;
-    if (attn_pipe_ok(a)) {       // key-block norms for the pipelined kernel's score bound (attn_pipe.hip): a few KiB, live for this op only
+    if (attn_pipe_ok(a) || attn_pipe128_ok(a)) {       // key-block norms for the pipelined kernels' score bound (attn_pipe.hip): a few KiB, live for this op only
         const size_t off = a_alloc((size_t)B * H * ((Mk + 63) / 64) * 4); a.knorm_ws = (float*)((uintptr_t)arena + off); a_free(off);
     }
     o.flops = 4.0 * B * H * (double)Nq * Mk * D;

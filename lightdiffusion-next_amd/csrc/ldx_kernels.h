@@ -128,7 +128,7 @@ struct AttnArgs {
     // O8 != null (only when attention_mx_out_ok(a)): the output is written as MX fp8 instead of 16-bit O — bytes
     // O8[b*Nq + n][h*D + d] (row stride ldo8) and, D being 128, one scale dword per (row, head): SO[h][b*Nq + n] (row stride so_ld)
     void* O8; int ldo8; uint32_t* SO; int so_ld;
-    // optional workspace of B * H * ceil(Mk / 64) floats (attn_pipe.hip): with it the pipelined D = 40 kernel proves most key blocks safe from the
+    // optional workspace of B * H * ceil(Mk / 64) floats (attn_pipe.hip, attn_pipe128.hip): with it the pipelined kernels prove most key blocks safe from the
     // norms of their keys (Cauchy-Schwarz) instead of taking the maximum of every score; null: the exact maximum on every block
     float* knorm_ws;
 };
@@ -140,6 +140,7 @@ bool attn_pipe_ok(const AttnArgs& a);
 void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 // The same pipeline for D = 128 (attn_pipe128.hip: Flux joint attention), 16-bit or MX fp8 output (AttnArgs::O8)
 bool attn_pipe128_ok(const AttnArgs& a);
+void launch_attn_knorm(const AttnArgs& a, DType dt, hipStream_t s);      // key-block norms for either pipelined kernel (AttnArgs::knorm_ws)
 void launch_attn_pipe128(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 
 // Cross-attention sub-block as one kernel (xattn_block.hip): H[m][:] += to_out(softmax(to_q(LayerNorm(H[m][:])) . K_b^T) . V_b) + bo, in place,
