@@ -585,7 +585,7 @@ void Engine::fuse_gn_stats() {
             const int bm = 128 * 320 / r.K;
             static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
             if (off || r.pro == 2 || r.Y != n.X || r.ldy != n.ldx || r.N != n.C || r.N != r.K || n.G != 32 || (long)r.M != (long)n.B * n.HW || n.HW % bm || n.HW / bm > gn_ws_rows ||
-                ((n.C / n.G) % 8 == 0 && (long)n.HW * (n.C / n.G) <= 256 * 80)) continue;      // last term: the one-launch small GroupNorm kernel takes it (norm.hip)
+                gn_uses_small_kernel(n.B, n.HW, n.C, n.G)) continue;      // last term: the one-launch small GroupNorm kernel takes it (norm.hip)
             r.gn_out = n.partial; r.gn_nchunk = n.HW / bm; r.HW = n.HW;
             n.stats_chunks = n.HW / bm;
             ops[i].bytes = 2.0 * 2.0 * (double)n.B * n.HW * n.C;

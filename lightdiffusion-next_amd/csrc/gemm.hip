@@ -486,7 +486,7 @@ static int splitk_gn_geom(const GemmArgs& a, int HW, int G, int max_chunks, int*
     if (nq > 512 || nq < 1) return 0;
     int R = nq <= 128 ? 8 : (nq <= 256 ? 4 : 2);        // a power of two (chunks of R rows must tile the image); up to 1024 threads: the kernel is latency-bound
     if (nq * R < 2 * G) return 0;
-    if ((a.N / G) % 8 == 0 && (long)HW * (a.N / G) <= 256 * 80) return 0;      // the one-launch small GroupNorm kernel takes this one (norm.hip): faster than apply-only
+    if (gn_uses_small_kernel(a.M / HW, HW, a.N, G)) return 0;      // the one-launch small GroupNorm kernel takes this one (norm.hip): faster than apply-only
 
     static const int lim_env = getenv("LDX_SKGN_CHUNKS") ? atoi(getenv("LDX_SKGN_CHUNKS")) : GN_NCHUNK;      // experiment switch: chunks per image (fewer = fatter workgroups)
     int lim = max_chunks < lim_env ? max_chunks : lim_env;

@@ -197,6 +197,9 @@ constexpr int GN_MAX_PRODUCER_CHUNKS = 32768;      // most partial rows per batc
 // floats of GroupNorm workspace for B images whose largest GroupNorm'ed map has HWmax pixels: producer rows (>= GN_NCHUNK) + the fold target
 static inline size_t gn_workspace_rows(long HWmax) { long r = HWmax / 64; if (r < GN_NCHUNK) r = GN_NCHUNK; if (r > GN_MAX_PRODUCER_CHUNKS) r = GN_MAX_PRODUCER_CHUNKS; return (size_t)r; }
 void launch_groupnorm(const GroupNormArgs& a, DType dt, hipStream_t s);
+// the dispatch rule of launch_groupnorm for its one-launch kernel (statistics + apply in one workgroup per (image, group)); the planner asks it too:
+// such a GroupNorm does not take producer-written statistics (LDX_GN_SMALL_MAX overrides the element bound)
+bool gn_uses_small_kernel(int B, long HW, int C, int G);
 
 // LayerNorm over the last dim C of [rows][ldx] -> [rows][ldy]
 // gamma/beta may be null (elementwise_affine=False); optional adaLN modulation (Flux):

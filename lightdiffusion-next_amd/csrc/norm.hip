@@ -271,6 +271,11 @@ __global__ __launch_bounds__(64) void gn_fold_kernel(const float* in, float* out
     out[((long)b * GN_FOLD + f) * G * 2 + t] = (a0 + a1) + (a2 + a3);
 }
 
+bool gn_uses_small_kernel(int B, long HW, int C, int G) {
+    static const long small_max = getenv("LDX_GN_SMALL_MAX") ? atol(getenv("LDX_GN_SMALL_MAX")) : 256 * 80;      // elements per (batch, group) the one-launch kernel takes
+    return G > 0 && (C / G) % 8 == 0 && HW * (C / G) <= small_max && (long)G * B >= 32;
+}
+
 template <typename T>
 static void launch_gn_t(const GroupNormArgs& a_in, hipStream_t s) {
     GroupNormArgs a = a_in;
@@ -293,8 +298,7 @@ static void launch_gn_t(const GroupNormArgs& a_in, hipStream_t s) {
         }
         return;
     }
-    static const long small_max = getenv("LDX_GN_SMALL_MAX") ? atol(getenv("LDX_GN_SMALL_MAX")) : 256 * 80;      // elements per (batch, group) the one-launch kernel takes
-    if ((a.C / a.G) % 8 == 0 && (long)a.HW * (a.C / a.G) <= small_max && a.G * a.B >= 32) {
+    if (gn_uses_small_kernel(a.B, a.HW, a.C, a.G)) {
         hipLaunchKernelGGL((gn_small_kernel<T>), dim3(a.G, a.B), dim3(256), 0, s, a);
         return;
     }

@@ -39,6 +39,11 @@ dt = (time.perf_counter() - t0) / n
 info = eng.plan_info()
 print(f"Flux DiT forward 1024^2 bs1 depth {depth}+{single}: {dt*1e3:.1f} ms  {info['flops']/dt/1e12:.0f} TFLOP/s ({info['flops']/1e12:.1f} TFLOP)  "
       f"launches {info['launches']} arena {info['arena_bytes']/2**30:.2f} GiB finite={bool(torch.isfinite(out).all())}")
+if os.environ.get("LDX_PROBE_SHAPES") == "1":      # per-op-shape table (ldx_profile mode 2) instead of the per-class one
+    eng._lib.ldx_profile(eng._h, 2, 1); eng.denoise(x, t, ctx, y, gd); torch.cuda.synchronize(); eng._lib.ldx_profile(eng._h, 0, 0)
+    for k, v in sorted(eng.profile_report().items(), key=lambda kv: -kv[1]["ms"])[:30]:
+        print(f"  {v['ms']:8.3f} ms  n={v['count']:4d} {1e3 * v['ms'] / max(v['count'], 1):8.1f} us/op" + (f"  {v['flops']/v['ms']/1e9:6.0f} TF" if v['flops'] else "          ") + f"  {k}")
+    sys.exit(0)
 eng.profile(True); eng.denoise(x, t, ctx, y, gd); torch.cuda.synchronize(); eng.profile(False, reset=False)
 for k, v in sorted(eng.profile_report().items(), key=lambda kv: -kv[1]["ms"])[:8]:
     print(f"  {k:30s} n={v['count']:4d} {v['ms']:.2f} ms" + (f"  {v['flops']/v['ms']/1e9:.0f} TF" if v['flops'] else ""))
