@@ -309,6 +309,9 @@ bool Engine::mk_res(const std::string& pre, int Cin, int Cout, ResW& r) {
     return true;
 }
 
+#ifndef LDX_LNFOLD_MAXROWS_DEFAULT
+#define LDX_LNFOLD_MAXROWS_DEFAULT 8192      // rows of a transformer level up to which its LayerNorms are folded into the consuming GEMMs (emit_xf)
+#endif
 static inline bool q_prescale() { static const bool on = getenv("LDX_NO_QPRESCALE") == nullptr; return on; }
 
 bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
@@ -331,7 +334,10 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         // Correct and tested, but measured neutral on MI355X (17.26 vs 17.14 ms per step): with every part of the fold switched off the
         // consuming GEMM is still 16 us slower at level 0 when it follows the GEMM that wrote h than when a LayerNorm launch sits between
         // them (50 -> 66 us; the statistics MFMAs, the LDS exchange and the epilogue add 8 more) - profiles/ubench/README.md.  Off by default.
-        static const bool fold_env = getenv("LDX_LNFOLD") != nullptr && atoi(getenv("LDX_LNFOLD")) != 0;
+        // Round 4: it does pay where the row-block kernels are not taken (512^2 step 6.01 -> 5.87 ms) and loses where they are (1024^2: 14.31 -> 15.04 with
+        // the fold everywhere), so both copies of the three weights are kept (+0.3 GB for SD1.5) and the planner decides per input shape
+        // (emit_xf: LDX_LNFOLD_MAXROWS); LDX_LNFOLD=0: plain weights only.
+        static const bool fold_env = !(getenv("LDX_LNFOLD") != nullptr && atoi(getenv("LDX_LNFOLD")) == 0);
         b.ln_fold = fold_env;
         // softmax_scale * log2(e) folded into the q projections at load time (one rounding of c * Wq instead of rounding q and multiplying
         // every score): the attention ops then run with scale = 1 / log2(e), i.e. exp2(q.k - m) as before; LDX_NO_QPRESCALE=1 keeps the plain weights
@@ -343,9 +349,10 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         const HostTensor* q2w = get(bp + ".attn2.to_q.weight", {C, C});
         if (!q2w) return false;
         if (b.ln_fold) {
-            if (!mk_ln_folded(3 * C, C, qkv_w, nullptr, bp + ".norm1", b.qkv, b.c1_qkv)) return false;
-            if (!mk_ln_folded(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c) * cq; }, nullptr, bp + ".norm2", b.q2, b.c1_q2)) return false;
-        } else {
+            if (!mk_ln_folded(3 * C, C, qkv_w, nullptr, bp + ".norm1", b.qkv_f, b.c1_qkv)) return false;
+            if (!mk_ln_folded(C, C, [&](size_t r, size_t c) { return q2w->at(r * C + c) * cq; }, nullptr, bp + ".norm2", b.q2_f, b.c1_q2)) return false;
+        }
+        {
             b.qkv.N = 3 * C; b.qkv.K = C; b.qkv.b = nullptr;
             b.qkv.w = upload16((size_t)3 * C, C, qkv_w);
             if (!b.qkv.w) return false;
@@ -370,8 +377,9 @@ bool Engine::mk_xf(const std::string& pre, int C, int depth, XfW& x) {
         auto src_row = [inner](size_t r) { const size_t slab = r / 64, within = r % 64; return within < 32 ? slab * 32 + within : inner + slab * 32 + (within - 32); };
         if (b.ln_fold) {
             if (!mk_ln_folded(2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); }, [&](size_t i) { return fb->at(src_row(i)); },
-                              bp + ".norm3", b.ff1, b.c1_ff1)) return false;
-        } else {
+                              bp + ".norm3", b.ff1_f, b.c1_ff1)) return false;
+        }
+        {
             b.ff1.N = 2 * inner; b.ff1.K = C;
             b.ff1.w = upload16((size_t)2 * inner, C, [&](size_t r, size_t c) { return fw->at(src_row(r) * C + c); });
             b.ff1.b = upload32((size_t)2 * inner, [&](size_t i) { return fb->at(src_row(i)); });
@@ -721,7 +729,12 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     // Folded LayerNorms (XfBlockW::ln_fold): the q|k|v / q / GEGLU GEMM reads h itself, accumulates each row's statistics from its own A
     // fragments and normalises in its epilogue (GemmArgs::ln_c1): no LayerNorm launch, no normalised copy of h.  A split-K consumer keeps a
     // plain (affine-free) LayerNorm launch in front of the folded weights.
-    const bool fold = x.depth > 0 && x.blocks[0].ln_fold;
+    // Per level: folded where the row-block kernels do not take the level's projections (fewer than ~192 row blocks) and the level is small (measured,
+    // same box: 512^2 step 6.00 -> 5.88 ms with all three levels folded, 430 -> 382 launches; 1024^2 14.23 -> 14.25 with only the 32^2 level folded
+    // (neutral), 14.29 when the 64^2 level's rowgemm launches are replaced too).  LDX_LNFOLD_MAXROWS moves the row limit (0: never).
+    static const long fold_maxrows = getenv("LDX_LNFOLD_MAXROWS") ? atol(getenv("LDX_LNFOLD_MAXROWS")) : LDX_LNFOLD_MAXROWS_DEFAULT;
+    const bool rowblocks = (C == 320 || C == 640) && rowblock_fills_chip(((long)M + 128 * 320 / C - 1) / (128 * 320 / C) * (C / 320));
+    const bool fold = x.depth > 0 && x.blocks[0].ln_fold && !rowblocks && (long)M <= fold_maxrows;
     Act n{};
     auto ln_gemm = [&](const char* ln_name, const char* name, const NormW& ln, const LinearW& w, const float* c1, Act Cc, bool geglu) {
         if (fold && gemm_choose_splitk(M, w.N, w.K, geglu) == 1) {
@@ -740,7 +753,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         const XfBlockW& b = x.blocks[d];
         Act qkv = new_act(M, 3 * C);
         if (fold || b.qkv.b || !op_rowgemm("xf.ln1+qkv", h, b.qkv, qkv, Act{}, 1, &b.ln1))        // LayerNorm + q|k|v projection as one launch (C = 320)
-            ln_gemm("xf.ln1", "xf.qkv", b.ln1, b.qkv, b.c1_qkv, qkv, false);
+            ln_gemm("xf.ln1", "xf.qkv", b.ln1, fold ? b.qkv_f : b.qkv, b.c1_qkv, qkv, false);
         Act a = new_act(M, C);
         const char* base = (const char*)ptr(qkv);
         op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
@@ -767,7 +780,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
             Act q = new_act(M, C);
             static const bool x2 = !(getenv("LDX_ROWGEMM_X2") && atoi(getenv("LDX_ROWGEMM_X2")) == 0);      // A/B switch for the two uses below
             if (!x2 || fold || b.q2.b || !op_rowgemm("xf.ln2+q2", h, b.q2, q, Act{}, 1, &b.ln2))          // C = 640: LayerNorm + q projection as one row-block launch
-                ln_gemm("xf.ln2", "xf.q2", b.ln2, b.q2, b.c1_q2, q, false);
+                ln_gemm("xf.ln2", "xf.q2", b.ln2, fold ? b.q2_f : b.q2, b.c1_q2, q, false);
             op_attn("xf.attn2", ptr(q), C, kvb, kv_total, kvb + (size_t)C * 2, kv_total, a, B, heads, H * W, Mc, D);
             if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
             release(q);
@@ -788,7 +801,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
             flops += o.flops;
         } else {
             Act f = new_act(M, 4 * C);
-            ln_gemm("xf.ln3", "xf.ff1", b.ln3, b.ff1, b.c1_ff1, f, true);        // GEGLU
+            ln_gemm("xf.ln3", "xf.ff1", b.ln3, fold ? b.ff1_f : b.ff1, b.c1_ff1, f, true);        // GEGLU
             op_gemm("xf.ff2", f, b.ff2, h, h);                     // x = ff(norm3(x)) + x
             release(f);
         }

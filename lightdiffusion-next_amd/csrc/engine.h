@@ -29,8 +29,9 @@ struct LinearW { void* w = nullptr; float* b = nullptr; int N = 0, K = 0;
 struct NormW { float* g = nullptr; float* b = nullptr; int C = 0; };
 struct ResW { NormW gn1, gn2; LinearW conv1, conv2, skip; bool has_skip = false; bool fused_skip = false; /* fused_skip: conv2 holds [W2 | Wskip], bias b2 + bskip */ int Cin = 0, Cout = 0; int emb_off = 0;
               float eps = 1e-5f; bool has_emb = true; };
-struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; int kv_off = 0;
-    // ln_fold: norm1/2/3 are folded into qkv / q2 / ff1 (weights W .* gamma, bias W beta + b, c1_* = row sums of the stored weights):
+struct XfBlockW { NormW ln1, ln2, ln3; LinearW qkv, o1, q2, kv2, o2, ff1, ff2; LinearW qkv_f, q2_f, ff1_f; /* LayerNorm-folded copies (ln_fold) */ int kv_off = 0;
+    // ln_fold: folded copies exist: norm1/2/3 folded into qkv_f / q2_f / ff1_f (weights W .* gamma, bias W beta + b, c1_* = row sums of the stored weights);
+    // the planner picks them per input shape (small row counts, where the row-block kernels are not taken):
     // the GEMM reads the un-normalised rows and applies rstd * (acc - mean * c1) + bias in its epilogue (GemmArgs::ln_stat)
     bool ln_fold = false; float *c1_qkv = nullptr, *c1_q2 = nullptr, *c1_ff1 = nullptr; };
 struct XfW { NormW gn; LinearW proj_in, proj_out; std::vector<XfBlockW> blocks; int C = 0, depth = 0; };
