@@ -731,10 +731,12 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     // plain (affine-free) LayerNorm launch in front of the folded weights.
     // Per level: folded where the row-block kernels do not take the level's projections (fewer than ~192 row blocks) and the level is small (measured,
     // same box: 512^2 step 6.00 -> 5.88 ms with all three levels folded, 430 -> 382 launches; 1024^2 14.23 -> 14.25 with only the 32^2 level folded
-    // (neutral), 14.29 when the 64^2 level's rowgemm launches are replaced too).  LDX_LNFOLD_MAXROWS moves the row limit (0: never).
+    // (neutral), 14.29 when the 64^2 level's rowgemm launches are replaced too; 8192 rows at C = 1280 (latent 256^2: HiresFix) lose 8 % of an evaluation:
+    // the folded GEGLU projection runs on the 128-row tiles instead of the ping-pong ones).  The limit is on rows x C; LDX_LNFOLD_MAXROWS moves it
+    // (rows at C = 320; 0: never).
     static const long fold_maxrows = getenv("LDX_LNFOLD_MAXROWS") ? atol(getenv("LDX_LNFOLD_MAXROWS")) : LDX_LNFOLD_MAXROWS_DEFAULT;
     const bool rowblocks = (C == 320 || C == 640) && rowblock_fills_chip(((long)M + 128 * 320 / C - 1) / (128 * 320 / C) * (C / 320));
-    const bool fold = x.depth > 0 && x.blocks[0].ln_fold && !rowblocks && (long)M <= fold_maxrows;
+    const bool fold = x.depth > 0 && x.blocks[0].ln_fold && !rowblocks && (long)M * C <= fold_maxrows * 320;      // 8192 rows at C = 320, 2048 at C = 1280
     Act n{};
     auto ln_gemm = [&](const char* ln_name, const char* name, const NormW& ln, const LinearW& w, const float* c1, Act Cc, bool geglu) {
         if (fold && gemm_choose_splitk(M, w.N, w.K, geglu) == 1) {
