@@ -183,24 +183,34 @@ class CFGDenoiser:
         sides = ([] if self.skip_uncond else [1] * len(neg)) + [0] * len(pos)
         ctxs = ([] if self.skip_uncond else list(reversed(neg))) + list(reversed(pos))
         ctxs = _lcm_pad_contexts(ctxs)
-        self.ctx = torch.cat(ctxs).contiguous()
+        # Device buffers live with the ENGINE, keyed by shape, not with this object: a new sampling run (new CFGDenoiser, new latent and context
+        # tensors) then presents the engine with the pointers of the previous run, and the hipGraph captured for the shape is replayed instead of
+        # re-captured (measured on the reference-default multi-scale "euler": 2 captures + 2 eager evaluations of every 20 went away).
+        import os
+        share = hasattr(engine, "__dict__") and os.environ.get("LDX_CFG_POOL", "1") != "0"      # 0: buffers private to this object (A/B switch)
+        self._pool = engine.__dict__.setdefault("_ldx_cfg_pool", {}) if share else {}
+        ctx = torch.cat(ctxs).contiguous()
+        key = ("ctx", tuple(ctx.shape))
+        if key not in self._pool:
+            self._pool[key] = torch.empty_like(ctx)
+        self._pool[key].copy_(ctx)
+        self.ctx = self._pool[key]
         self.sides = sides                                  # cond_or_uncond of the batch
         self.n_entries = len(sides)
         self.nb = self.n_entries * batch
         self.batch = batch
         self.simple = (not self.skip_uncond) and sides == [1, 0]
-        self._bufs = {}
-        self._xsrc = {}         # per input shape: [data_ptr of the caller's x, persistent staging tensor or None]
 
     def _buffers(self, shape):
-        key = tuple(shape)
-        if key not in self._bufs:
+        key = ("bufs", self.nb, tuple(shape))
+        if key not in self._pool:
             b, c, h, w = shape
             dev = self.engine.device
-            self._bufs[key] = (torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32),
+            self._pool[key] = (torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32),
                                torch.empty((self.nb,), device=dev, dtype=torch.float32),
-                               torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32))
-        return self._bufs[key]
+                               torch.empty((self.nb, c, h, w), device=dev, dtype=torch.float32),
+                               torch.empty((b, c, h, w), device=dev, dtype=torch.float32))      # staging copy of x for ldx_unet_denoise_cfg
+        return self._pool[key]
 
     def _side(self, out, side):
         """calc_cond_batch's accumulation for one side: sum of the entries' outputs in batch order / count (cond.py:262-288)."""
@@ -215,20 +225,14 @@ class CFGDenoiser:
 
     def __call__(self, x, sigma):
         """Returns (denoised_uncond, denoised_cond), each [B,4,h,w] fp32."""
-        xin, sig, out = self._buffers(x.shape)
+        xin, sig, out, xstage = self._buffers(x.shape)
         b = self.batch
-        if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.is_contiguous() and x.dtype == torch.float32:
-            # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg): no torch copy / fill kernels in the loop.  The engine's captured
-            # graph is tied to the pointer of x: a sampler that updates x in place (euler, dpmpp_2m) keeps handing over the same tensor and is
-            # passed through; one that alternates tensors (dpmpp_sde's x / x2, the multi-scale steps' fresh _bilinear outputs) would invalidate
-            # the graph on every call, so from the first change of pointer on this shape goes through ONE persistent staging tensor (one small
-            # device copy per evaluation instead of an eager ~350-launch forward or a re-capture).
-            src = self._xsrc.setdefault(tuple(x.shape), [x.data_ptr(), None])
-            if src[1] is None and src[0] != x.data_ptr():
-                src[1] = torch.empty_like(x)
-            if src[1] is not None:
-                src[1].copy_(x)
-                x = src[1]
+        if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.dtype == torch.float32:
+            # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg).  The engine's captured graph is tied to the pointers it was
+            # captured with, and samplers hand over different tensors (dpmpp_sde's x / x2, the multi-scale steps' fresh _bilinear outputs, every new
+            # sampling run): x always goes through the engine-lifetime staging tensor of its shape (one 256 KiB device copy per evaluation).
+            xstage.copy_(x)
+            x = xstage
             self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out)
             return out[:b], out[b:]
         for i in range(self.n_entries):                     # the general case (cfg 1 / several entries per side): host-side batch assembly
