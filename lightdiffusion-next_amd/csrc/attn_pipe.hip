@@ -173,6 +173,13 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
         rs[i] = make_uint4(v[0], v[1], v[2], v[3]);
     };
     auto gload = [&](uint4 (&rs)[3], int kblk, int vblk) __attribute__((always_inline)) { gload1(rs, 0, kblk, vblk); gload1(rs, 1, kblk, vblk); gload1(rs, 2, kblk, vblk); };
+    // the same loads from running byte offsets (the slot loop keeps them in SGPRs: add + clamp per stream instead of min + multiply per load)
+    auto gload1o = [&](uint4 (&rs)[3], int i, unsigned kofs, unsigned vofs) __attribute__((always_inline)) {
+        const auto v = i == 0 ? __builtin_amdgcn_raw_buffer_load_b128(rK, gofs[0], kofs, 0)
+                     : (i == 1 ? __builtin_amdgcn_raw_buffer_load_b128(r1, gofs[1], r1k ? kofs : vofs, 0)
+                               : __builtin_amdgcn_raw_buffer_load_b128(rV, gofs[2], vofs, 0));
+        rs[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    };
     // asm with an AGPR data operand: the staging loads then land in AGPRs (with a VGPR home hipcc spilled them to AGPRs right behind the load,
     // i.e. vmcnt(0) three times per slot); hipcc still sees the load -> use dependency and places the vmcnt wait in front of the store
     auto lstore1 = [&](const uint4 (&rs)[3], int i, int slot) __attribute__((always_inline)) {
@@ -286,7 +293,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
     // One barrier per slot: tiles stored in slot t - 1 (gaps 17-21) become readable behind it (V(t) fragments right after it, K(t+2) fragments
     // from gap 16), and this slot's stores overwrite ring slots whose last readers (slot t - 1, behind its barrier) every wave has passed before
     // it arrives.  Raw s_barrier + lgkmcnt(0) only: the staging loads issued at the top of the slot stay in flight across it.
-    auto slot = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], ap_i32x4 (&pp)[2][4], ap_i32x4 (&pc)[2][4], V8 (&vfc)[4][2], V8 (&vfn)[4][2], uint4 (&rsl)[3], const uint4 (&rss)[3], auto PAR) __attribute__((always_inline)) {
+    auto slot = [&](int t, f32x16 (&sc)[2][2], f32x16 (&sn)[2][2], ap_i32x4 (&pp)[2][4], ap_i32x4 (&pc)[2][4], V8 (&vfc)[4][2], V8 (&vfn)[4][2], uint4 (&rsl)[3], const uint4 (&rss)[3], auto PAR, unsigned kofs, unsigned vofs) __attribute__((always_inline)) {
         constexpr int par = decltype(PAR)::value;    // t & 1: ring slots are compile-time constants
         float kn = 0.f, bm0 = 0.f, bm1 = 0.f;
         // gap g: MFMA g (QK^T(t+1) for g < 12, PV(t-1) after), then its fillers from the schedule (ApSched): staging loads in gaps 0-2, the slot's
@@ -303,7 +310,7 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
                 __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (g < 12) qk1(G, sn); else pv1(ap_ic<g - 12>{}, pp, vfc);
-            if constexpr (g < 3 && !(ABL & 8)) gload1(rsl, g, t + 4, t + 2);                                              // stored in slot t + 1 (a whole slot of latency cover)
+            if constexpr (g < 3 && !(ABL & 8)) gload1o(rsl, g, kofs, vofs);                                              // stored in slot t + 1 (a whole slot of latency cover)
             if constexpr (KB && g == 3) kn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rN, 0, min(t + 1, nblk - 1) * 4, 0));      // max ||k|| of block t + 1 (same for every lane)
             if constexpr (g >= S::BAR && g < S::BAR + 8 && !(ABL & 16)) vread1(vfn, (g - S::BAR) >> 1, (g - S::BAR) & 1, par);      // V(t), staged in slot t - 1
             if constexpr (g >= 16 && g < 22 && !(ABL & 16)) kread1((g - 16) >> 1, (g - 16) & 1, par);                  // K(t+2), staged in slot t - 1
@@ -356,9 +363,14 @@ __global__ __launch_bounds__(256, 1) void attn40p_kernel(const AttnArgs p, const
             if (__builtin_amdgcn_ballot_w64(ap_max2(bm0, bm1) > thr) != 0) raise_reference();
         }
     };
+    // byte offsets of the tiles slot t loads: K(t + 4), V(t + 2), clamped to the last block
+    const unsigned klast = (unsigned)(nblk - 1) * kstep, vlast = (unsigned)(nblk - 1) * vstep;
+    unsigned kofs = min(4u * kstep, klast), vofs = min(2u * vstep, vlast);
     for (int t = 0; t < nblk; t += 2) {
-        slot(t, sA, sB, pA, pB, vfA, vfB, rsA, rsB, ap_ic<0>{});
-        slot(t + 1, sB, sA, pB, pA, vfB, vfA, rsB, rsA, ap_ic<1>{});
+        slot(t, sA, sB, pA, pB, vfA, vfB, rsA, rsB, ap_ic<0>{}, kofs, vofs);
+        kofs = min(kofs + kstep, klast); vofs = min(vofs + vstep, vlast);
+        slot(t + 1, sB, sA, pB, pA, vfB, vfA, rsB, rsA, ap_ic<1>{}, kofs, vofs);
+        kofs = min(kofs + kstep, klast); vofs = min(vofs + vstep, vlast);
     }
     ap_for(ap_range<0, 16>(), [&](auto J) __attribute__((always_inline)) { pv1(J, pA, vfA); });      // P(nblk-1) (nblk even: written by the odd slot into pA) x V(nblk-1)
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15" ::: "memory");

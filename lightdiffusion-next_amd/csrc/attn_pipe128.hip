@@ -137,6 +137,13 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
                              : __builtin_amdgcn_raw_buffer_load_b128(rV, gofV, vblk * vstep + (i - 4) * rstepV, 0);
         rs[i] = make_uint4(v[0], v[1], v[2], v[3]);
     };
+    // the same loads from running byte offsets of the two tiles (kept in SGPRs by the block loop: add + clamp per block instead of min + multiply per load)
+    auto gload1o = [&](auto I, unsigned kofs, unsigned vofs) __attribute__((always_inline)) {
+        constexpr int i = decltype(I)::value;
+        const auto v = i < 4 ? __builtin_amdgcn_raw_buffer_load_b128(rK, gofK, kofs + i * rstepK, 0)
+                             : __builtin_amdgcn_raw_buffer_load_b128(rV, gofV, vofs + (i - 4) * rstepV, 0);
+        rs[i] = make_uint4(v[0], v[1], v[2], v[3]);
+    };
     auto lstore1 = [&](auto I, int kring, int vring) __attribute__((always_inline)) {
         constexpr int i = decltype(I)::value;
         const ap_i32x4 w = ap_bits(rs[i]);
@@ -248,7 +255,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
     //                 before any exponential of sn is taken
     //   staging       K(t+2) -> K ring r2, V(t+1) -> V ring r1 (their last readers ran in block t - 1, in front of this block's barrier); the register
     //                 of a stored chunk is reloaded with K(t+3) / V(t+2) right away
-    auto halfslot = [&](auto PARC, int t, f32x16 (&sc)[2], f32x16 (&sn)[2], ap_i32x4 (&pp)[2][2], ap_i32x4 (&pc)[2][2], int r0, int r1, int r2) __attribute__((always_inline)) {
+    auto halfslot = [&](auto PARC, int t, f32x16 (&sc)[2], f32x16 (&sn)[2], ap_i32x4 (&pp)[2][2], ap_i32x4 (&pc)[2][2], int r0, int r1, int r2, unsigned kofs, unsigned vofs) __attribute__((always_inline)) {
         constexpr int PAR = decltype(PARC)::value;
         const char* kp = smem + (PAR ? r1 : r0) * KBYTES + (1 - PAR) * 32 * KROWB + lane_k;      // this half-slot's keys
         const char* kpn = smem + r1 * KBYTES + PAR * 32 * KROWB + lane_k;                         // the next half-slot's: fragments 0..2 for its first MFMAs
@@ -266,7 +273,7 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
             if constexpr ((g & 1) == 0 && g <= 8 && !(ABL & 16)) kfr[(g / 2 + 3) & 3] = as_v8<T>(*(const uint4*)(kp + (g / 2 + 3) * 32));
             if constexpr ((g & 1) == 0 && g >= 10 && g <= 24 && !(ABL & 16)) vread(ap_ic<(g - 10) / 2>{}, vp);
             if constexpr ((g == 26 || g == 28 || g == 30) && !(ABL & 16)) kfr[(g - 26) / 2] = as_v8<T>(*(const uint4*)(kpn + ((g - 26) / 2) * 32));
-            if constexpr ((g & 7) == 5 && !(ABL & 8)) { lstore1(ap_ic<4 * PAR + (g >> 3)>{}, r2, r1); gload1(ap_ic<4 * PAR + (g >> 3)>{}, t + 3, t + 2); }
+            if constexpr ((g & 7) == 5 && !(ABL & 8)) { lstore1(ap_ic<4 * PAR + (g >> 3)>{}, r2, r1); gload1o(ap_ic<4 * PAR + (g >> 3)>{}, kofs, vofs); }
             if constexpr (KB && g == 3) kn = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rN, 0, min(t + PAR, nblk - 1) * 4, 0));      // max ||k|| of the block sn belongs to
             if constexpr (!(ABL & 32)) half(G, sc, pc);
             if constexpr (!KB) {
@@ -320,10 +327,13 @@ __global__ __launch_bounds__(256, 1) void attn128p_kernel(const AttnArgs p, cons
         }
     };
     int r0 = 0, r1 = 1, r2 = 2;
+    const unsigned klast = (unsigned)(nblk - 1) * kstep, vlast = (unsigned)(nblk - 1) * vstep;
+    unsigned kofs = min(3u * kstep, klast), vofs = min(2u * vstep, vlast);      // block t loads K(t + 3), V(t + 2), clamped to the last block
     for (int t = 0; t < nblk; ++t) {
-        halfslot(ap_ic<0>{}, t, sX, sY, pR, pQ, r0, r1, r2);
-        halfslot(ap_ic<1>{}, t, sY, sX, pQ, pR, r0, r1, r2);
+        halfslot(ap_ic<0>{}, t, sX, sY, pR, pQ, r0, r1, r2, kofs, vofs);
+        halfslot(ap_ic<1>{}, t, sY, sX, pQ, pR, r0, r1, r2, kofs, vofs);
         const int x = r0; r0 = r1; r1 = r2; r2 = x;
+        kofs = min(kofs + kstep, klast); vofs = min(vofs + vstep, vlast);
     }
     // keys 32-63 of block nblk - 1 (pR) x V(nblk-1), stored in block nblk - 2; r2 = (nblk - 1) % 3 here
     {
