@@ -95,6 +95,13 @@ if __name__ == "__main__":
         gemm(8192, 8192, 8192, reps=2)
     if what == "attn1":
         attn(reps=3)
+    if what == "attnsmall":    # the short-sequence launches of the deeper SD1.5 levels (grids below one workgroup per CU)
+        for (n, d) in ((1024, 160), (1024, 80), (256, 160), (4096, 80)):
+            qkv = torch.randn(2, n, 3 * 8 * d, device="cuda").bfloat16(); Cn = 8 * d
+            O = torch.empty(2, n, Cn, device="cuda", dtype=torch.bfloat16)
+            fn = lambda: L.ldx_op_attention(p(qkv), 3 * Cn, p(qkv[..., Cn:]), 3 * Cn, p(qkv[..., 2 * Cn:]), 3 * Cn, p(O), Cn, 2, 8, n, n, d, 1 / math.sqrt(d), 0, 0, st())
+            us = timeit_graph(fn, 40) * 1e3
+            print(f"attn B2 H8 N{n} D{d}: {us:.1f} us  {4.0 * 2 * 8 * n * n * d / us / 1e6:.0f} TFLOP/s")
     if what == "attn128":      # one Flux joint-attention launch
         attn(B=1, H=24, N=4352, D=128, reps=3)
     if what == "gemm640":      # a plain mid-size projection (SD1.5 64^2 level)
