@@ -68,3 +68,15 @@ def test_graph_is_replayed_across_sde_and_multiscale_steps(ldx, g, unet):
     print(f"dpmpp_sde_cfgpp graph mode: {evals} evaluations, {captures} captures, {replays} replays")
     assert torch.equal(out, eager)
     assert evals == 39 and captures <= 4 and replays >= evals - 10, (evals, captures, replays)
+    # round 4: the device buffers (context, batch, staging copy of x) live with the engine per shape, so a SECOND sampling run — new CFGDenoiser, new
+    # latent and context tensors — presents the same pointers: nothing is captured again, every evaluation replays
+    e.set_graph_mode(True)
+    try:
+        trace2 = []
+        out2 = ks.sample(trace=trace2, **kw)
+    finally:
+        e.set_graph_mode(False)
+    c2, r2 = e.graph_stats()
+    print(f"second run: {len(trace2)} evaluations, {c2 - c1} captures, {r2 - r1} replays")
+    assert torch.equal(out2, eager)
+    assert c2 - c1 == 0 and r2 - r1 == len(trace2), (c2 - c1, r2 - r1, len(trace2))
