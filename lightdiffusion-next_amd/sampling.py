@@ -195,6 +195,10 @@ class CFGDenoiser:
             self._pool[key] = torch.empty_like(ctx)
         self._pool[key].copy_(ctx)
         self.ctx = self._pool[key]
+        # the shared context buffer holds THIS object's context only while it is the owner: another CFGDenoiser of the same shape on the same engine
+        # (created later, used in between) overwrites it, and __call__ then restores it from the private copy
+        self._ctx_src, self._ctx_key = ctx, ("ctx_owner",) + key[1:]
+        self._pool[self._ctx_key] = self
         self.sides = sides                                  # cond_or_uncond of the batch
         self.n_entries = len(sides)
         self.nb = self.n_entries * batch
@@ -226,6 +230,9 @@ class CFGDenoiser:
     def __call__(self, x, sigma):
         """Returns (denoised_uncond, denoised_cond), each [B,4,h,w] fp32."""
         xin, sig, out, xstage = self._buffers(x.shape)
+        if self._pool.get(self._ctx_key) is not self:
+            self.ctx.copy_(self._ctx_src)
+            self._pool[self._ctx_key] = self
         b = self.batch
         if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.dtype == torch.float32:
             # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg).  The engine's captured graph is tied to the pointers it was

@@ -80,3 +80,19 @@ def test_graph_is_replayed_across_sde_and_multiscale_steps(ldx, g, unet):
     print(f"second run: {len(trace2)} evaluations, {c2 - c1} captures, {r2 - r1} replays")
     assert torch.equal(out2, eager)
     assert c2 - c1 == 0 and r2 - r1 == len(trace2), (c2 - c1, r2 - r1, len(trace2))
+
+
+def test_two_denoisers_on_one_engine_do_not_share_a_context(ldx, g, unet):
+    """The context / batch buffers of CFGDenoiser live with the engine per shape (round 4).  Two denoisers of the same shape with DIFFERENT prompts,
+    used alternately, must each see their own context: the shared buffer is restored from the private copy when its owner changed."""
+    e = unet["f16"]
+    P, N = torch.from_numpy(g["P"]), torch.from_numpy(g["N"])
+    d1 = ldx.sampling.CFGDenoiser(e, P, N, 7.0, 1, 16, 16)
+    d2 = ldx.sampling.CFGDenoiser(e, P * 0.5 + 0.1, N, 7.0, 1, 16, 16)
+    x = torch.randn(1, 4, 16, 16, generator=torch.Generator().manual_seed(3)).cuda()
+    a1 = [t.clone() for t in d1(x, 3.0)]
+    a2 = [t.clone() for t in d2(x, 3.0)]
+    b1 = [t.clone() for t in d1(x, 3.0)]
+    b2 = [t.clone() for t in d2(x, 3.0)]
+    assert torch.equal(a1[1], b1[1]) and torch.equal(a2[1], b2[1])
+    assert not torch.equal(a1[1], a2[1])
