@@ -171,7 +171,11 @@ class CFGDenoiser:
     ([neg_last .. neg_0, pos_last .. pos_0] x B; cond_or_uncond == [1, .., 0, ..], cond.py:186-195), every context repeated to the lcm of the
     lengths (cond.py:100-126), and gives each side the mean of its entries' outputs (full area, multiplier 1: ksampler_util.py:106-149 of this
     snapshot; start_percent / end_percent are computed by calculate_start_end_timesteps but never consulted, so they are not mirrored).
-    With one entry per side this is the [uncond x B ; cond x B] batch of ldx_unet_denoise_cfg."""
+    With one entry per side this is the [uncond x B ; cond x B] batch of ldx_unet_denoise_cfg.
+
+    The device buffers (context, batch assembly, output) belong to the ENGINE, one set per shape, so that consecutive sampling runs replay the same
+    hipGraphs.  The pair returned by __call__ are views of the engine's output buffer of that shape: valid until the next evaluation of the same
+    shape on the same engine (by this or another CFGDenoiser) — the samplers consume them before they call the model again, like the reference's."""
 
     def __init__(self, engine, positive, negative, cfg, batch, h, w, disable_cfg1_optimization=False):
         self.engine, self.cfg = engine, float(cfg)
