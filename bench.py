@@ -69,6 +69,11 @@ def parse_args(argv=None):
     ap.add_argument("--no-configs", action="store_true", help="skip the config 3 / 4 / 5 secondary lines (Flux weights take ~1.5 min to build)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--tiny", action="store_true", help="debug: tiny UNet config")
+    ap.add_argument("--preflight", action="store_true",
+                    help="multi-GPU smoke: init the process group, one 256 KiB all-gather through torch.distributed AND the direct RCCL path, print one JSON "
+                         "line (ranks, backend, per-rank device / NUMA node) and exit — seconds, before any weight work")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the 20-step reference-golden comparison after the timed regions")
+    ap.add_argument("--private-weights", action="store_true", help="N > 1: every rank synthesises its own state dict (default: local rank 0 publishes one under /dev/shm)")
     ap.add_argument("--stub-engine", action="store_true",
                     help="TEST ONLY (tests/test_bench_gloo.py): CPU + gloo, an analytic per-sample stand-in for the UNet; the line is marked stub")
     return ap.parse_args(argv)
@@ -84,6 +89,7 @@ def self_launch(args):
     """No torchrun environment and N > 1: re-execute under torch.distributed.run, one rank per GPU."""
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["LDX_RCCL_NONCE"] = f"{os.getpid()}.{time.time_ns()}"          # names this launch: stale hand-off files of earlier runs are ignored (parallel.py)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
     return subprocess.run(cmd, env=env).returncode
@@ -377,6 +383,68 @@ def hiresfix_line(ldx, unet, cfg):
             "esrgan_roofline": _roof(einfo["flops"], 1e3 * med(3), PEAK_BF16_TFLOPS, "RRDBNet x4, 512^2 tile (flops incl. channel padding)")}
 
 
+def run_preflight(ldx, dist, rank, world, local_rank, dev, stub):
+    """A topology failure must cost seconds and be NAMED: one 256 KiB all-gather through torch.distributed (asserted) and, on GPUs, the same through
+    the direct RCCL path (guarded, reported), plus every rank's device / NUMA node / host cpus.  Runs before any weight work."""
+    t0 = time.perf_counter()
+    n = 65536                                                     # 256 KiB of fp32 per rank
+    mine = torch.full((n,), float(rank), dtype=torch.float32, device=dev)
+    chunks = [torch.empty_like(mine) for _ in range(world)]
+    dist.all_gather(chunks, mine)
+    if not stub:
+        torch.cuda.synchronize()
+    for r, c in enumerate(chunks):
+        assert float(c[0]) == float(r) and float(c[-1]) == float(r), f"preflight all-gather: chunk {r} holds {float(c[0])}"
+    t_pg = time.perf_counter() - t0
+    info = {"rank": rank, "local_rank": local_rank, "host": socket.gethostname(), "pid": os.getpid(),
+            "device": (None if stub else torch.cuda.get_device_name(local_rank)),
+            "numa_node": (None if stub else ldx.parallel.gpu_numa_node(local_rank)),
+            "cpus_allowed": len(os.sched_getaffinity(0)), "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES")}
+    infos = [None] * world
+    dist.all_gather_object(infos, info)
+    direct = None
+    if not stub:
+        try:
+            def _xchg(r, make_id):
+                box = [make_id() if r == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                return box[0]
+            td0 = time.perf_counter()
+            comm = ldx.parallel.RcclComm(rank, world, id_exchange=_xchg)
+            got = comm.all_gather_latents(mine.view(1, n), world)
+            torch.cuda.synchronize()
+            ok = all(float(got[r, 0]) == float(r) for r in range(world))
+            comm.close()
+            direct = {"ok": bool(ok), "s": round(time.perf_counter() - td0, 3)}
+        except Exception as e:      # noqa: BLE001 — reported in the line
+            direct = {"ok": False, "error": repr(e)[:300]}
+    return {"world": world, "backend": dist.get_backend(), "allgather_256KiB_ok": True, "process_group_s": round(t_pg, 3),
+            "rccl_direct": direct, "ranks": infos}
+
+
+def parity_check(ldx, eng, dtype):
+    """Did the timed loop time the RIGHT work?  Runs BASELINE config 2 exactly as the reference golden was captured (oracle/ref_capture_full20.py:
+    KSampler.sample, sample_euler / normal, 20 steps, cfg 7, seed 42, multiscale off, zero latent 128^2, the fixture's own prompt tensors) through the
+    same engine object the timed regions used, and compares with the reference's latents.  Fixture only: the oracle stays out of this."""
+    import numpy as np
+    path = os.path.join(ROOT, "tests", "golden", "unet_full20.npz")
+    try:
+        z = np.load(path)
+        want = torch.from_numpy(z["ks128_20_out"]).double()
+        P, N = torch.from_numpy(z["P"]), torch.from_numpy(z["N"])
+    except Exception as e:          # fixture absent: say so instead of inventing a number
+        return {"ok": False, "error": repr(e)[:200]}
+    tol = {"bf16": 5e-2, "f16": 1e-2, "fp16": 1e-2}[dtype]
+    ks = ldx.sampling.KSampler(eng)
+    got = ks.sample(seed=42, steps=20, cfg=7.0, sampler_name="sample_euler", scheduler="normal", enable_multiscale=False,
+                    positive=P, negative=N, latent_image=torch.zeros(1, 4, 128, 128)).double().cpu()
+    rel = float((got - want).norm() / want.norm())
+    cos = float(torch.dot(got.flatten(), want.flatten()) / (got.norm() * want.norm()))
+    return {"rel_l2": round(rel, 6), "cos": round(cos, 7), "tol": tol, "cos_min": 0.999, "ok": bool(rel <= tol and cos >= 0.999),
+            "against": "tests/golden/unet_full20.npz ks128_20_out = the reference's own KSampler.sample latents (20 steps, 1024x1024, cfg 7, seed 42)",
+            "latents_sha256_16": hashlib.sha256(got.float().contiguous().numpy().tobytes()).hexdigest()[:16]}
+
+
 # ------------------------------------------------------------------------------------------------------
 def main(argv=None):
     args = parse_args(argv)
@@ -408,22 +476,59 @@ def main(argv=None):
         dev = torch.device("cuda", local_rank)
         sync = torch.cuda.synchronize
 
-    if world > 1:
-        # N ranks build the same 859.5 M synthetic parameters at once: each gets the cores of its GPU's NUMA node (its share of them), not N x all
-        import ldx_amd.parallel as par
-        cpus = par.bind_rank_to_numa(local_rank, world) if not stub else list(range(max(1, (os.cpu_count() or 1) // world)))
-        torch.set_num_threads(max(1, len(cpus)))
     import ldx_amd as ldx
+    t_start = time.perf_counter()
+    preflight = None
+    if world > 1:
+        preflight = run_preflight(ldx, dist, rank, world, local_rank, dev, stub)      # before any weight work
+    if args.preflight:
+        if preflight is None:
+            preflight = {"world": 1, "backend": None, "ranks": [{"rank": 0, "device": (None if stub else torch.cuda.get_device_name(local_rank)),
+                                                                  "numa_node": (None if stub else ldx.parallel.gpu_numa_node(local_rank))}]}
+        if rank == 0:
+            print(json.dumps({"preflight": preflight, "n_gpus": world}), flush=True)
+        if dist:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    if world > 1:
+        # N ranks convert the same 859.5 M parameters at once: each gets the cores of its GPU's NUMA node (its share of them), not N x all
+        cpus = ldx.parallel.bind_rank_to_numa(local_rank, local_world) if not stub else list(range(max(1, (os.cpu_count() or 1) // world)))
+        torch.set_num_threads(max(1, len(cpus)))
     cfg = ldx.UNetConfig.tiny(64, 128) if args.tiny else ldx.UNetConfig.sd15()
     sd = None
+    build = {}
     if stub:
         eng = StubEngine()
     else:
         spec = ldx.weights.unet_state_dict_spec(cfg)
-        sd = ldx.weights.synth_state_dict(spec, seed=1234)
+        tb0 = time.perf_counter()
+        if world > 1 and not args.private_weights:
+            # ONE synthesis per node: local rank 0 writes the state dict under /dev/shm, the others map it (weights.publish_state_dict)
+            shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"ldx_sd_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.bin")
+            if local_rank == 0:
+                sd = ldx.weights.publish_state_dict(spec, shm, seed=1234)
+            dist.barrier()
+            if local_rank != 0:
+                sd = ldx.weights.attach_state_dict(spec, shm)
+            dist.barrier()
+            if local_rank == 0:
+                os.unlink(shm)                                   # the mappings stay valid; nothing is left behind in /dev/shm
+            build["weights"] = "shared: local rank 0 synthesised, the others mapped /dev/shm"
+        else:
+            sd = ldx.weights.synth_state_dict(spec, seed=1234)
+            build["weights"] = "private synthesis"
+        tb1 = time.perf_counter()
         eng = ldx.UNetEngine(cfg, sd, device=local_rank, dtype=args.dtype)
+        build.update(state_dict_s=round(tb1 - tb0, 2), engine_build_s=round(time.perf_counter() - tb1, 2), since_start_s=round(time.perf_counter() - t_start, 2))
         if not args.no_graph:
             eng.set_graph_mode(True)
+    if dist:
+        builds = [None] * world
+        dist.all_gather_object(builds, build)
+    else:
+        builds = [build]
 
     lat = args.latent
     if args.config == 3:
@@ -635,6 +740,14 @@ def main(argv=None):
                     secondary[key] = r
                 torch.cuda.empty_cache()
 
+    # ---- did the timed regions time the right work?  (N = 1, headline engine, after every timed region; fixture comparison only) ----
+    parity = None
+    if rank == 0 and world == 1 and not stub and not args.tiny and not args.no_parity_check:
+        try:
+            parity = parity_check(ldx, eng, args.dtype)
+        except Exception as e:      # noqa: BLE001 — reported in the line
+            parity = {"ok": False, "error": repr(e)[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and not stub and not args.no_cpu_baseline and not args.tiny:
         cpu = cpu_baseline(cfg, sd)
@@ -667,8 +780,9 @@ def main(argv=None):
                        "allgather_ms": round(1000.0 * statistics.median(gathers_max), 3),
                        "allgather_bytes": int(gathered.numel() * 4), "rccl_direct": rccl_direct, "config3_e2e": e2e3,
                        "backend": (dist.get_backend() if dist else None), "rccl_ranks": (dist.get_world_size() if dist else 1),
-                       "latents_sha256_16": hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16]},
-            "roofline": roof, "cpu_baseline": cpu, "secondary": secondary,
+                       "latents_sha256_16": hashlib.sha256(gathered.detach().cpu().contiguous().numpy().tobytes()).hexdigest()[:16],
+                       "engine_build": builds, "preflight": preflight},
+            "roofline": roof, "cpu_baseline": cpu, "parity_check": parity, "secondary": secondary,
         }
         print(json.dumps(line), flush=True)
     if dist:

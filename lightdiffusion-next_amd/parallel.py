@@ -57,7 +57,21 @@ _NCCL_FLOAT32 = 7          # ncclDataType_t: ncclFloat32 (nccl.h)
 
 
 class _NcclUniqueId(_C.Structure):
-    _fields_ = [("internal", _C.c_char * NCCL_UNIQUE_ID_BYTES)]
+    # c_ubyte, not c_char: a c_char array field reads back NUL-terminated, and real ids hold zero bytes (magic, sockaddr, padding)
+    _fields_ = [("internal", _C.c_ubyte * NCCL_UNIQUE_ID_BYTES)]
+
+
+def unique_id_to_bytes(uid: "_NcclUniqueId") -> bytes:
+    """All 128 bytes of the struct (bytes(struct) copies the whole buffer, zeros included)."""
+    raw = bytes(uid)
+    assert len(raw) == NCCL_UNIQUE_ID_BYTES, len(raw)
+    return raw
+
+
+def unique_id_from_bytes(raw: bytes) -> "_NcclUniqueId":
+    if len(raw) != NCCL_UNIQUE_ID_BYTES:
+        raise ValueError(f"RCCL unique id must be {NCCL_UNIQUE_ID_BYTES} bytes, got {len(raw)}")
+    return _NcclUniqueId.from_buffer_copy(raw)
 
 
 def load_rccl(path: str = None):
@@ -74,15 +88,32 @@ def load_rccl(path: str = None):
     return lib
 
 
-def exchange_unique_id_file(path: str, rank: int, make_id, timeout_s: float = 120.0) -> bytes:
-    """Rank 0 calls make_id() -> 128 bytes and publishes them at `path` (written to a temporary name, then renamed: readers never see a partial
-    file); every other rank waits for the file.  Returns the id on every rank."""
+RUN_NONCE_BYTES = 16
+
+
+def _run_nonce(nonce=None) -> bytes:
+    """16 bytes that name THIS launch (the launcher exports LDX_RCCL_NONCE to every rank): a file left behind by an earlier or crashed run at the
+    same path carries another nonce and is ignored by the readers instead of being taken for rank 0's id."""
+    import hashlib
+    text = nonce if nonce is not None else _os.environ.get("LDX_RCCL_NONCE", "")
+    return hashlib.sha256(text.encode()).digest()[:RUN_NONCE_BYTES]
+
+
+def exchange_unique_id_file(path: str, rank: int, make_id, timeout_s: float = 120.0, nonce: str = None) -> bytes:
+    """Rank 0 calls make_id() -> 128 bytes and publishes nonce + id at `path` (stale file removed first; written to a temporary name, then renamed:
+    readers never see a partial file); every other rank waits for a file that carries ITS run nonce.  Returns the id on every rank."""
+    tag = _run_nonce(nonce)
     if rank == 0:
         uid = bytes(make_id())
-        assert len(uid) == NCCL_UNIQUE_ID_BYTES, len(uid)
+        if len(uid) != NCCL_UNIQUE_ID_BYTES:
+            raise ValueError(f"RCCL unique id must be {NCCL_UNIQUE_ID_BYTES} bytes, got {len(uid)}")
+        try:
+            _os.unlink(path)
+        except FileNotFoundError:
+            pass
         tmp = f"{path}.tmp.{_os.getpid()}"
         with open(tmp, "wb") as f:
-            f.write(uid)
+            f.write(tag + uid)
             f.flush()
             _os.fsync(f.fileno())
         _os.replace(tmp, path)
@@ -91,9 +122,9 @@ def exchange_unique_id_file(path: str, rank: int, make_id, timeout_s: float = 12
     while True:
         try:
             with open(path, "rb") as f:
-                uid = f.read()
-            if len(uid) == NCCL_UNIQUE_ID_BYTES:
-                return uid
+                blob = f.read()
+            if len(blob) == RUN_NONCE_BYTES + NCCL_UNIQUE_ID_BYTES and blob[:RUN_NONCE_BYTES] == tag:
+                return blob[RUN_NONCE_BYTES:]
         except FileNotFoundError:
             pass
         if _time.monotonic() - t0 > timeout_s:
@@ -112,18 +143,26 @@ class RcclComm:
         def make_id():
             uid = _NcclUniqueId()
             self._check(self.lib.ncclGetUniqueId(_C.byref(uid)), "ncclGetUniqueId")
-            return bytes(uid.internal)
+            return unique_id_to_bytes(uid)
 
         if id_exchange is None:
             path = _os.environ.get("LDX_RCCL_ID_FILE")
             if not path:
                 raise RuntimeError("RcclComm: set LDX_RCCL_ID_FILE (a path every rank of the node can read) or pass id_exchange")
             id_exchange = lambda r, mk: exchange_unique_id_file(path, r, mk)
+            id_path = path
+        else:
+            id_path = None
+        self._id_path = id_path
         raw = id_exchange(rank, make_id)
-        uid = _NcclUniqueId()
-        _C.memmove(_C.byref(uid), raw, NCCL_UNIQUE_ID_BYTES)
+        uid = unique_id_from_bytes(bytes(raw))
         self.comm = _C.c_void_p()
         self._check(self.lib.ncclCommInitRank(_C.byref(self.comm), world, uid, rank), "ncclCommInitRank")
+        if rank == 0 and self._id_path:          # every rank has joined once rank 0's init returns: the id file has done its job
+            try:
+                _os.unlink(self._id_path)
+            except OSError:
+                pass
 
     def _check(self, rc, what):
         if rc != 0:
@@ -192,8 +231,11 @@ def plan_rank_cpus(allowed, node_of_rank, node_cpus, local_rank: int):
 
 
 def gpu_numa_node(device_index: int) -> int:
-    """NUMA node of a visible GPU from sysfs (PCI address from the device properties); -1 when the platform does not say."""
+    """NUMA node of a visible GPU from sysfs (PCI address from the device properties); -1 when the platform does not say or the index is not
+    visible to THIS process (per-rank HIP_VISIBLE_DEVICES: every rank only sees its own GPU as device 0)."""
     try:
+        if device_index < 0 or device_index >= torch.cuda.device_count():
+            return -1
         pr = torch.cuda.get_device_properties(device_index)
         bdf = f"{pr.pci_domain_id:04x}:{pr.pci_bus_id:02x}:{pr.pci_device_id:02x}.0"
         with open(f"/sys/bus/pci/devices/{bdf}/numa_node") as f:
@@ -203,7 +245,10 @@ def gpu_numa_node(device_index: int) -> int:
 
 
 def bind_rank_to_numa(local_rank: int, local_world: int):
-    """Restrict this process to its share of the cores next to its GPU; returns the CPU list (also the torch thread count to use)."""
+    """Restrict this process to its share of the cores next to its GPU; returns the CPU list (also the torch thread count to use).
+    local_world = ranks on THIS node (LOCAL_WORLD_SIZE).  When the ranks were given one visible GPU each (HIP_VISIBLE_DEVICES / ROCR_VISIBLE_DEVICES),
+    the peers' GPUs cannot be queried from here: this rank's own node is looked up as device 0 and the node's cores are split among all local ranks
+    that could share it (an even split of the node: never worse than the un-bound default, never an empty set)."""
     import glob
     import os
     allowed = sorted(os.sched_getaffinity(0))
@@ -214,7 +259,16 @@ def bind_rank_to_numa(local_rank: int, local_world: int):
                 nodes[int(os.path.basename(d)[4:])] = parse_cpulist(f.read())
         except Exception:
             pass
-    node_of_rank = [gpu_numa_node(r) for r in range(local_world)]
+    masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")) and torch.cuda.device_count() < local_world
+    if masked:
+        mine = gpu_numa_node(0)
+        n_nodes = max(1, len(nodes))
+        # peers unknown: assume the launcher spread the ranks evenly over the nodes in rank order (rank r -> node r * n_nodes // local_world)
+        node_of_rank = [(r * n_nodes // local_world) if mine >= 0 else -1 for r in range(local_world)]
+        if mine >= 0:
+            node_of_rank[local_rank] = mine
+    else:
+        node_of_rank = [gpu_numa_node(r) for r in range(local_world)]
     cpus = plan_rank_cpus(allowed, node_of_rank, nodes, local_rank)
     try:
         os.sched_setaffinity(0, cpus)

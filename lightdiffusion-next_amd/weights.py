@@ -170,6 +170,53 @@ def synth_state_dict(spec, seed: int = 1234, dtype=torch.float16) -> Dict[str, t
     return {k: synth_tensor(k, s, seed, dtype) for k, s in spec}
 
 
+# ---- one synthetic state dict per NODE (multi-GPU start-up): rank 0 builds it once into a file under /dev/shm, the other ranks map that file.
+# Eight ranks x 859.5 M parameters synthesised in parallel cost 30-40 s of host work each and fight for one socket's memory bandwidth; the mapped
+# copy costs the page-cache read only.  Layout: tensors in spec order at 64-byte aligned offsets, raw little-endian elements, no header — both
+# sides derive every offset from (spec, dtype), so the file holds data only.
+def state_dict_layout(spec, dtype=torch.float16):
+    """[(key, shape, byte offset, byte length)], total bytes."""
+    esz = torch.empty((), dtype=dtype).element_size()
+    out, off = [], 0
+    for k, shp in spec:
+        n = 1
+        for d in shp:
+            n *= d
+        out.append((k, tuple(shp), off, n * esz))
+        off = (off + n * esz + 63) // 64 * 64
+    return out, max(off, 64)
+
+
+def _map_state_dict(path, spec, dtype, create):
+    layout, total = state_dict_layout(spec, dtype)
+    buf = torch.from_file(path, shared=True, size=total, dtype=torch.uint8) if create else torch.from_file(path, shared=False, size=total, dtype=torch.uint8)
+    return {k: buf[off:off + nb].view(dtype).reshape(shp) for k, shp, off, nb in layout}, buf
+
+
+def publish_state_dict(spec, path: str, seed: int = 1234, dtype=torch.float16) -> Dict[str, torch.Tensor]:
+    """Build synth_state_dict(spec, seed, dtype) INTO a file at `path` (written under a temporary name, then renamed: a reader never maps a partial
+    file) and return it as views of the mapping.  Bit-identical to synth_state_dict."""
+    import os
+    tmp = f"{path}.tmp.{os.getpid()}"
+    sd, buf = _map_state_dict(tmp, spec, dtype, create=True)
+    for k, shp in spec:
+        sd[k].copy_(synth_tensor(k, shp, seed, dtype))
+    del sd, buf                                     # unmap: the shared mapping's pages are the file's pages
+    os.replace(tmp, path)
+    return attach_state_dict(spec, path, dtype)
+
+
+def attach_state_dict(spec, path: str, dtype=torch.float16) -> Dict[str, torch.Tensor]:
+    """Map a file written by publish_state_dict (private copy-on-write mapping: nothing a rank does to its tensors reaches the others)."""
+    import os
+    _, total = state_dict_layout(spec, dtype)
+    have = os.path.getsize(path)
+    if have != total:
+        raise RuntimeError(f"shared state dict {path}: {have} bytes, expected {total} (another model / dtype, or a stale file)")
+    sd, _ = _map_state_dict(path, spec, dtype, create=False)
+    return sd
+
+
 def param_count(spec) -> int:
     n = 0
     for _, s in spec:

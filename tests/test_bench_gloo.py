@@ -66,3 +66,15 @@ def test_eight_ranks_config3_even_and_uneven_global_batch():
         assert eight["config"]["global_batch"] == gb and eight["config"]["images_per_gpu"] == -(-gb // 8) and eight["scaling"] == "strong"
         assert eight["timing"]["allgather_bytes"] == gb * 4 * 8 * 8 * 4
         assert one["timing"]["latents_sha256_16"] == eight["timing"]["latents_sha256_16"], gb
+
+
+def test_preflight_two_ranks_prints_topology_and_exits():
+    """`bench.py --gpus N --preflight` (round 5): process group + one 256 KiB all-gather + per-rank device info, no weight work; and the normal
+    N > 1 run carries the same object in `timing.preflight` (it runs before the engine is built)."""
+    p = _run(["--gpus", "2", "--preflight"])
+    pf = _line(p)
+    assert pf["n_gpus"] == 2 and pf["preflight"]["world"] == 2 and pf["preflight"]["backend"] == "gloo"
+    assert pf["preflight"]["allgather_256KiB_ok"] is True
+    assert [r["rank"] for r in pf["preflight"]["ranks"]] == [0, 1] and pf["preflight"]["ranks"][0]["pid"] != pf["preflight"]["ranks"][1]["pid"]
+    two = _line(_run(["--gpus", "2", "--batch", "1"]))
+    assert two["timing"]["preflight"]["world"] == 2 and len(two["timing"]["engine_build"]) == 2

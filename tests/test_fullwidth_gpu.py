@@ -73,6 +73,23 @@ def test_ksampler_full_width_vs_reference(full, ldx, dt, tol):
     assert r <= tol and c >= 0.999
 
 
+@pytest.mark.parametrize("lat", [64, 128])
+@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+def test_ksampler_20_steps_full_width_vs_reference(full, ldx, golden_dir, lat, dt, tol):
+    """BASELINE configs 1 (512^2) and 2 (1024^2 = the headline bench.py times) END TO END: 20 sample_euler / normal steps, cfg 7, seed 42, multiscale
+    off, against the reference's own KSampler.sample latents (tests/golden/unet_full20.npz from oracle/ref_capture_full20.py).  bench.py's
+    `parity_check` repeats the 128^2 bf16 case on the driver-timed engine."""
+    cfg, sd, g, eng = full
+    z = np.load(os.path.join(golden_dir, "unet_full20.npz"))
+    ks = ldx.sampling.KSampler(eng[dt])
+    out = ks.sample(seed=42, steps=20, cfg=7.0, sampler_name="sample_euler", scheduler="normal", enable_multiscale=False,
+                    positive=torch.from_numpy(z["P"]), negative=torch.from_numpy(z["N"]), latent_image=torch.zeros(1, 4, lat, lat))
+    want = z[f"ks{lat}_20_out"]
+    r, c = _rel(out, want), _cos(out, want)
+    print(f"[{dt}] full-width KSampler 20 steps at {lat}^2 vs reference: rel-L2 {r:.3e} cos {c:.6f} (tol {tol})")
+    assert r <= tol and c >= 0.999
+
+
 def test_full_width_vs_oracle_on_this_box(full):
     """The CPU restatement at full width on the GPU box's host cores (a few seconds at 64^2) against the engine AND the golden."""
     cfg, sd, g, eng = full

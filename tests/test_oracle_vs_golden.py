@@ -124,6 +124,30 @@ def test_ksampler_img2img(tiny):
     assert _rel(out, g["ks_img2img"]) < 1e-3
 
 
+def test_full_width_20_steps_config1_vs_reference(ldx, golden_dir):
+    """BASELINE config 1 END TO END at full width (859.5 M parameters): the reference's own KSampler.sample latents for 20 sample_euler / normal
+    steps at 512x512 (oracle/ref_capture_full20.py, ks64_20) against the oracle's sampler chain — ~50 s of CPU.  The per-step rms trace
+    pins every one of the 20 model calls, not only the final latents."""
+    g = np.load(os.path.join(golden_dir, "unet_full20.npz"))
+    cfg = ldx.UNetConfig.sd15()
+    sd = {k: v.float() for k, v in ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=1234).items()}
+    rms = []
+
+    def model(x, s, c):
+        o = O.apply_model(sd, cfg, x, s, c)
+        rms.append(float(o.float().pow(2).mean().sqrt()))
+        return o
+
+    with torch.no_grad():
+        out = O.ksampler_sample(model, seed=42, steps=20, cfg=7.0, positive=torch.from_numpy(g["P"]), negative=torch.from_numpy(g["N"]),
+                                latent_image=torch.zeros(1, 4, 64, 64), sampler_name="sample_euler", scheduler="normal", enable_multiscale=False)
+    r = _rel(out, g["ks64_20_out"])
+    print(f"oracle vs reference, 20 steps at 64^2 full width: rel-L2 {r:.3e}")
+    assert r < 1e-3
+    assert len(rms) == 20
+    np.testing.assert_allclose(np.array(rms), g["ks64_20_trace"], rtol=1e-3)
+
+
 def test_state_dict_layout_matches_survey(ldx):
     spec = ldx.weights.unet_state_dict_spec(ldx.UNetConfig.sd15())
     assert len(spec) == 686 and ldx.weights.param_count(spec) == 859_520_964      # SURVEY.md Appendix B

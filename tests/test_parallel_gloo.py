@@ -71,3 +71,54 @@ def test_shard_bounds_cover(ldx):
             spans = [ldx.parallel.shard_bounds(total, r, world) for r in range(world)]
             assert spans[0][0] == 0 and spans[-1][1] == total
             assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+
+
+def _sd_worker(rank, world, port, path, q):
+    """bench.py's start-up protocol for the shared synthetic state dict: local rank 0 publishes, barrier, the others map, barrier, rank 0 unlinks."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    import ldx_amd as ldx
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = ldx.UNetConfig.tiny(64, 128)
+    spec = ldx.weights.unet_state_dict_spec(cfg)
+    sd = ldx.weights.publish_state_dict(spec, path, seed=1234) if rank == 0 else None
+    dist.barrier()
+    if rank != 0:
+        sd = ldx.weights.attach_state_dict(spec, path)
+    dist.barrier()
+    if rank == 0:
+        os.unlink(path)
+    want = ldx.weights.synth_state_dict(spec, seed=1234)
+    ok = set(sd) == set(want) and all(sd[k].dtype == want[k].dtype and torch.equal(sd[k], want[k]) for k in want)
+    if rank != 0:                       # a rank's writes must stay private (copy-on-write mapping)
+        sd[spec[0][0]].zero_()
+    dist.barrier()
+    ok = ok and (rank != 0 or torch.equal(sd[spec[0][0]], want[spec[0][0]]))
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shared_state_dict_equals_private_synthesis(ldx, tmp_path):
+    """Round 5 (multi-GPU start-up): one synthesis per node through a mapped file == every rank's own synth_state_dict, bit for bit."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.SimpleQueue()
+    port = _free_port()
+    path = str(tmp_path / "sd.bin")
+    procs = [ctx.Process(target=_sd_worker, args=(r, world, port, path, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get() for _ in procs)
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    assert res == {0: True, 1: True}
+    assert not os.path.exists(path)
+    with pytest.raises(RuntimeError):                                   # a file of another model is refused, not mis-mapped
+        spec = ldx.weights.unet_state_dict_spec(ldx.UNetConfig.tiny(64, 128))
+        with open(path, "wb") as f:
+            f.write(b"\0" * 128)
+        ldx.weights.attach_state_dict(spec, path)

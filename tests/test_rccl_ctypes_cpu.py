@@ -44,6 +44,43 @@ def test_unique_id_file_handoff_across_processes(ldx, tmp_path):
         ldx.parallel.exchange_unique_id_file(str(tmp_path / "never"), 1, make_id=None, timeout_s=0.2)
 
 
+def test_unique_id_with_nul_bytes_round_trips_through_the_struct(ldx):
+    """Real ncclUniqueIds hold zero bytes (magic, sockaddr, padding): the struct <-> bytes conversion must keep all 128 (a c_char array
+    field reads back NUL-terminated and cut the id at its first zero)."""
+    par = ldx.parallel
+    raw = bytes([7, 0, 0, 9] + [0] * 60 + list(range(64)))
+    assert len(raw) == 128
+    uid = par.unique_id_from_bytes(raw)
+    assert par.unique_id_to_bytes(uid) == raw
+    with pytest.raises(ValueError):
+        par.unique_id_from_bytes(raw[:5])
+
+    class FakeLib:                       # ncclGetUniqueId writes an id with NULs; ncclCommInitRank must receive exactly those bytes
+        seen = None
+        def ncclGetUniqueId(self, p):
+            import ctypes
+            ctypes.memmove(p, raw, 128); return 0
+        def ncclCommInitRank(self, comm, world, uid, rank):
+            FakeLib.seen = bytes(uid); return 0
+        def ncclCommDestroy(self, c): return 0
+        def ncclGetErrorString(self, rc): return b"fake"
+    comm = par.RcclComm(0, 1, id_exchange=lambda r, mk: mk(), lib=FakeLib())
+    assert FakeLib.seen == raw
+    comm.close()
+
+
+def test_stale_id_file_of_another_run_is_ignored(ldx, tmp_path):
+    par = ldx.parallel
+    path = str(tmp_path / "id")
+    old = bytes(range(128))
+    assert par.exchange_unique_id_file(path, 0, make_id=lambda: old, nonce="run-A") == old
+    with pytest.raises(TimeoutError):                       # a reader of run B must not take run A's file
+        par.exchange_unique_id_file(path, 1, make_id=None, timeout_s=0.3, nonce="run-B")
+    new = bytes(reversed(range(128)))
+    assert par.exchange_unique_id_file(path, 0, make_id=lambda: new, nonce="run-B") == new
+    assert par.exchange_unique_id_file(path, 1, make_id=None, timeout_s=5, nonce="run-B") == new
+
+
 @pytest.mark.parametrize("total,world", [(8, 2), (10, 8), (5, 2), (64, 8)])
 def test_unpad_matches_shard_bounds(ldx, total, world):
     per = (total + world - 1) // world
