@@ -434,7 +434,7 @@ def parity_check(ldx, eng, dtype):
         P, N = torch.from_numpy(z["P"]), torch.from_numpy(z["N"])
     except Exception as e:          # fixture absent: say so instead of inventing a number
         return {"ok": False, "error": repr(e)[:200]}
-    tol = {"bf16": 5e-2, "f16": 1e-2, "fp16": 1e-2}[dtype]
+    tol = {"bf16": 3e-2, "f16": 5e-3, "fp16": 5e-3}[dtype]          # measured 1.8e-2 / 2.0e-3 (tests/test_fullwidth_gpu.py)
     ks = ldx.sampling.KSampler(eng)
     got = ks.sample(seed=42, steps=20, cfg=7.0, sampler_name="sample_euler", scheduler="normal", enable_multiscale=False,
                     positive=P, negative=N, latent_image=torch.zeros(1, 4, 128, 128)).double().cpu()

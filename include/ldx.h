@@ -149,6 +149,15 @@ int ldx_unet_denoise_concat(ldx_engine* e, const float* x_nchw, const float* sig
  * ldx_unet_denoise on the concatenated inputs (bit-identical); replaces two device copies and a fill per sampler step. */
 int ldx_unet_denoise_cfg(ldx_engine* e, const float* x_nchw, float sigma, const float* ctx,
                          int B, int h, int w, int M, float* out_nchw, void* stream);
+/* Context cache for a sampling run.  The reference recomputes to_k(context) / to_v(context) of all 16 cross-attentions in every step
+ * (CrossAttention.forward, src/Attention/Attention.py:100-124, called from transformer.py:186-245) although `c_crossattn` is the same tensor content
+ * for every step of a run (calc_cond_batch rebuilds it from the same conditioning, cond/cond.py:150-288).  enable = 1: the CALLER PROMISES that the
+ * bytes behind a given ctx pointer stay unchanged until its next call of this function (any argument); the engine then converts / projects the
+ * context once per (input shape, ctx pointer) and every later ldx_unet_denoise* call with that pointer reuses the projections (identical bits:
+ * the same kernels produced them).  Every call of this function — also with enable = 1 again — INVALIDATES what is cached: call it after
+ * rewriting a context buffer in place.  enable = 0 (the default): projections recomputed on every call, as the reference does.
+ * The hook object (LdxUNetPatch) leaves it off: the reference hands the hook a fresh torch.cat every step. */
+int ldx_unet_context_cache(ldx_engine* e, int enable);
 /* Raw UNetModel1.forward (unet.py:679-770): x (already scaled), integer timesteps given as fp32. */
 int ldx_unet_forward(ldx_engine* e, const float* x_nchw, const float* timesteps, const float* ctx,
                      int B2, int h, int w, int M, float* out_nchw, void* stream);
@@ -170,6 +179,9 @@ int ldx_set_graph_mode(ldx_engine* e, int enable);
  * created (a captured graph is tied to the pointers of the call that recorded it: a caller that alternates buffers re-captures instead of
  * replaying — sampling.CFGDenoiser stages such inputs through one persistent buffer per shape). */
 int ldx_graph_stats(ldx_engine* e, int64_t* captures, int64_t* replays);
+/* The kernel-dispatch experiment switches (LDX_ATTN_PIPE, LDX_ATTN_PIPE128, LDX_ATTN_PIPE_MINWG, LDX_ATTN_PIPE_THR) are read ONCE when the library
+ * is loaded — no getenv on the launch path.  Tests and same-process A/B runs that change them afterwards call this to re-read them. */
+int ldx_reload_env(void);
 
 /* ---- VAE decode and CLIP text encode (same ldx_engine handle type; load/finalize/destroy as above) ---------- */
 /* Keys for ldx_load_tensor: the reference's first_stage_model state dict ("decoder.*", "post_quant_conv.*"). */

@@ -1006,32 +1006,40 @@ static void launch_attn_d(const AttnArgs& a, hipStream_t s) {
     else launch_attn_t<T, 5, 11>(a, s);
 }
 
+// Dispatch switches of launch_attention, read ONCE (static initialisation) — the launch path itself never calls getenv.
+// Experiments and tests that flip a switch inside one process call reload_dispatch_env() (C ABI: ldx_reload_env) after changing the environment.
+struct AttnSwitches { bool pipe40, pipe128; long minwg40, minwg128; float thr; };
+static AttnSwitches read_attn_switches() {
+    AttnSwitches w;
+    const char* e = getenv("LDX_ATTN_PIPE");
+    const char* e128 = getenv("LDX_ATTN_PIPE128");
+    const char* m = getenv("LDX_ATTN_PIPE_MINWG");
+    const char* t = getenv("LDX_ATTN_PIPE_THR");
+    w.pipe40 = !e || atoi(e) != 0;
+    w.pipe128 = !e128 || atoi(e128) != 0;
+    w.minwg40 = m ? atol(m) : 256;
+    w.minwg128 = m ? atol(m) : 192;
+    w.thr = t ? (float)atof(t) : __builtin_nanf("");          // NaN = the type's own rescale threshold
+    return w;
+}
+static AttnSwitches g_attn_sw = read_attn_switches();
+void reload_dispatch_env() { g_attn_sw = read_attn_switches(); }
+
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {
     if (a.Nq <= 0 || a.B <= 0) return;
+    const AttnSwitches& w = g_attn_sw;
+    if (attn512_ok(a)) { launch_attn512(a, dt, s); return; }      // one head of D = 512 (VAE mid-block attention): attn512.hip
     // D = 40 self-attention of the large levels: the software-pipelined one-wave-per-SIMD kernel (attn_pipe.hip) when its 256-query workgroups
-    // fill the chip.  LDX_ATTN_PIPE=0 restores attn32ap / attn32; LDX_ATTN_PIPE_THR=<x> overrides the rescale threshold (tests).  Read per call:
-    // one process A/Bs both kernels.
-    if (attn_pipe_ok(a)) {
-        const char* e = getenv("LDX_ATTN_PIPE");
-        const char* m = getenv("LDX_ATTN_PIPE_MINWG");
-        const long wgs = (long)(a.Nq / 256) * a.H * a.B;
-        if ((!e || atoi(e) != 0) && wgs >= (m ? atol(m) : 256)) {
-            const char* t = getenv("LDX_ATTN_PIPE_THR");
-            launch_attn_pipe(a, dt, s, t ? (float)atof(t) : __builtin_nanf(""));
-            return;
-        }
+    // fill the chip.  LDX_ATTN_PIPE=0 restores attn32ap / attn32; LDX_ATTN_PIPE_THR=<x> overrides the rescale threshold (tests).
+    if (w.pipe40 && attn_pipe_ok(a) && (long)(a.Nq / 256) * a.H * a.B >= w.minwg40) {
+        launch_attn_pipe(a, dt, s, w.thr);
+        return;
     }
     // D = 128 (Flux): the same pipeline (attn_pipe128.hip) when one round of its 256-query workgroups covers at least three quarters of the CUs.
     // O8 (MX fp8 output) needs attention_mx_out_ok(), i.e. the attn32g D = 128 variant enabled: the callers' test, unchanged.
-    if (attn_pipe128_ok(a)) {
-        const char* e = getenv("LDX_ATTN_PIPE128");
-        const char* m = getenv("LDX_ATTN_PIPE_MINWG");
-        const long wgs = (long)(a.Nq / 256) * a.H * a.B;
-        if ((!e || atoi(e) != 0) && wgs >= (m ? atol(m) : 192)) {
-            const char* t = getenv("LDX_ATTN_PIPE_THR");
-            launch_attn_pipe128(a, dt, s, t ? (float)atof(t) : __builtin_nanf(""));
-            return;
-        }
+    if (w.pipe128 && attn_pipe128_ok(a) && (long)(a.Nq / 256) * a.H * a.B >= w.minwg128) {
+        launch_attn_pipe128(a, dt, s, w.thr);
+        return;
     }
     if (dt == DT_BF16) launch_attn_d<__bf16>(a, s); else launch_attn_d<_Float16>(a, s);
 }

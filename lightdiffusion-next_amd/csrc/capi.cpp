@@ -269,7 +269,7 @@ int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float*
 int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     if (n_launches) *n_launches = e->impl->n_launches();
-    if (flops) *flops = e->impl->flops;
+    if (flops) *flops = e->impl->steady_flops();
     if (arena_bytes) *arena_bytes = (int64_t)e->impl->arena_cap;
     return LDX_OK;
 }
@@ -290,6 +290,15 @@ int ldx_profile_report(ldx_engine* e, char* buf, int64_t cap) {
 int ldx_set_graph_mode(ldx_engine* e, int enable) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     e->impl->graph_mode = enable != 0;
+    return LDX_OK;
+}
+int ldx_unet_context_cache(ldx_engine* e, int enable) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_context_cache: not a UNet engine"); return LDX_ESTATE; }
+    return e->impl->set_context_cache(enable);
+}
+int ldx_reload_env(void) {
+    reload_dispatch_env();
     return LDX_OK;
 }
 int ldx_graph_stats(ldx_engine* e, int64_t* captures, int64_t* replays) {
@@ -460,8 +469,13 @@ int ldx_op_layernorm(const void* X, int ldx_, void* Y, int ldy, int rows, int C,
 }
 int ldx_op_attention(const void* Q, int ldq, const void* K, int ldk, const void* V, int ldv, void* O, int ldo, int B, int H, int Nq, int Mk, int D,
                      float scale, int causal, int dtype, void* stream) {
-    if (!Q || !K || !V || !O || D % 8 || D > 160 || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160)"); return LDX_EINVAL; }
+    if (!Q || !K || !V || !O || D % 8 || (D > 160 && D != 512) || D <= 0 || ldq % 8 || ldk % 8 || ldv % 8 || ldo % 4 || Mk <= 0) { set_error("ldx_op_attention: bad argument (D % 8, D <= 160 or D == 512)"); return LDX_EINVAL; }
     AttnArgs a{Q, ldq, K, ldk, V, ldv, O, ldo, B, H, Nq, Mk, D, scale, causal, nullptr, 0, 0};
+    if (D == 512) {
+        if (!attn512_ok(a)) { set_error("ldx_op_attention: D = 512 without a mask only (attn512.hip)"); return LDX_EINVAL; }
+        a.nsplit = attn512_splits(a);
+        if (a.nsplit > 1) { a.split_ws = op_workspace(attn512_ws_floats(a, a.nsplit)); if (!a.split_ws) { set_error("attention split workspace allocation failed"); return LDX_EHIP; } }
+    }
     if (attn_pipe_ok(a) || attn_pipe128_ok(a)) a.knorm_ws = op_workspace((size_t)B * H * ((Mk + 63) / 64));      // (shared single-op scratch: one stream per device, include/ldx.h)
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention");

@@ -483,6 +483,7 @@ int Engine::finalize() {
     }
     emb_srcs.clear(); kv_srcs.clear();
     host.clear();
+    { const int rc2 = build_emb_table(); if (rc2) return rc2; }
     finalized = true;
     return LDX_OK;
 }
@@ -527,6 +528,9 @@ void Engine::a_free(size_t off) {
 
 // Tile counters of the in-kernel split-K reduction (GemmArgs::sk_count): the engine's launches run in stream order and each leaves them at zero.
 unsigned* Engine::sk_counters() {
+#ifndef LDX_SK_FIXUP_BUILD
+    return nullptr;                         // the in-kernel split-K reduction is not compiled in (gemm_sk_fixup() is constant false): no counters
+#endif
     if (!d_sk_count) {
         if (hipMalloc((void**)&d_sk_count, sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { d_sk_count = nullptr; return nullptr; }
         if (hipMemset(d_sk_count, 0, sizeof(unsigned) * SK_COUNTERS) != hipSuccess) { (void)hipFree(d_sk_count); d_sk_count = nullptr; return nullptr; }
@@ -670,12 +674,17 @@ void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, in
     if (attn_pipe_ok(a) || attn_pipe128_ok(a)) {       // key-block norms for the pipelined kernels' score bound (attn_pipe.hip): a few KiB, live for this op only
         const size_t off = a_alloc((size_t)B * H * ((Mk + 63) / 64) * 4); a.knorm_ws = (float*)((uintptr_t)arena + off); a_free(off);
     }
+    if (attn512_ok(a)) {              // D = 512 (VAE): key splits when the query blocks alone leave CUs idle; fp32 partials live for this op only
+        a.nsplit = attn512_splits(a);
+        if (a.nsplit > 1) { const size_t off = a_alloc(attn512_ws_floats(a, a.nsplit) * 4); a.split_ws = (float*)((uintptr_t)arena + off); a_free(off); }
+    }
     o.flops = 4.0 * B * H * (double)Nq * Mk * D;
     o.bytes = 2.0 * (double)B * H * D * (2.0 * Nq + 2.0 * Mk);
     {
         const int ks = D <= 32 ? 1 : D <= 64 ? 2 : D <= 96 ? 3 : D <= 128 ? 4 : 5;
         const int dtl = D / 16 + 1;
-        snprintf(o.klabel, sizeof(o.klabel), "attn_kernel<%s,%d,%d>%s", dt == DT_BF16 ? "bf16" : "f16", ks, dtl, Nq == Mk ? "self" : "cross");
+        if (attn512_ok(a)) snprintf(o.klabel, sizeof(o.klabel), "attn512_kernel<%s>x%d", dt == DT_BF16 ? "bf16" : "f16", a.nsplit);
+        else snprintf(o.klabel, sizeof(o.klabel), "attn_kernel<%s,%d,%d>%s", dt == DT_BF16 ? "bf16" : "f16", ks, dtl, Nq == Mk ? "self" : "cross");
     }
     ops.push_back(o);
     flops += o.flops;
@@ -860,14 +869,17 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         Act xin = new_act(B2 * h * w, 64);
         prep_xc_off = xin.off;
         Act ctx16 = new_act(B2 * Mc, cfg.context_dim);
-        { Op o{}; o.kind = OP_CVT; o.name = "ctx.cvt"; o.cvt_out = ptr(ctx16); o.cvt_n = (size_t)B2 * Mc * cfg.context_dim; ops.push_back(o); }
-        { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.0"; o.sk = SkinnyArgs{d_temb_out, mc, te0.w, te0.b, d_e1, ted, B2, ted, mc, 0, 1}; ops.push_back(o); }
-        { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.2"; o.sk = SkinnyArgs{d_e1, ted, te2.w, te2.b, d_e2, ted, B2, ted, ted, 0, 1}; ops.push_back(o); }
-        { Op o{}; o.kind = OP_SKINNY; o.name = "emb_layers"; o.sk = SkinnyArgs{d_e2, ted, emb_all.w, emb_all.b, d_emb_all, emb_total, B2, emb_total, ted, 0, 0}; ops.push_back(o); }
-        flops += 2.0 * B2 * ((double)ted * mc + (double)ted * ted + (double)emb_total * ted);
+        { Op o{}; o.kind = OP_CVT; o.name = "ctx.cvt"; o.cvt_out = ptr(ctx16); o.cvt_n = (size_t)B2 * Mc * cfg.context_dim; o.ctx_only = true; ops.push_back(o); }
+        if (!d_emb_table) {       // per-step time-embedding MLP (LDX_EMB_TABLE=0); otherwise the prep kernel gathers the timestep's row of the table
+            { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.0"; o.sk = SkinnyArgs{d_temb_out, mc, te0.w, te0.b, d_e1, ted, B2, ted, mc, 0, 1}; ops.push_back(o); }
+            { Op o{}; o.kind = OP_SKINNY; o.name = "time_embed.2"; o.sk = SkinnyArgs{d_e1, ted, te2.w, te2.b, d_e2, ted, B2, ted, ted, 0, 1}; ops.push_back(o); }
+            { Op o{}; o.kind = OP_SKINNY; o.name = "emb_layers"; o.sk = SkinnyArgs{d_e2, ted, emb_all.w, emb_all.b, d_emb_all, emb_total, B2, emb_total, ted, 0, 0}; ops.push_back(o); }
+            flops += 2.0 * B2 * ((double)ted * mc + (double)ted * ted + (double)emb_total * ted);
+        }
         Act kvall = new_act(B2 * Mc, kv_total);
         kv_all_off = kvall.off;
         op_gemm("xf.kv2_all", ctx16, kv_all, kvall, Act{});
+        ops.back().ctx_only = true;
 
         int lv = 0, s = 0;
         Act hcur = skip_view(0);
@@ -960,7 +972,36 @@ int Engine::plan(int B2, int h, int w, int Mc) {
     }
     pB2 = B2; ph = h; pw = w; pM = Mc;
     graph_valid = false; warm = false;
+    kv_ptr = nullptr; kv_epoch = 0;          // a fresh arena holds no projected context
     return LDX_OK;
+}
+
+// The 22 emb_layers outputs for EVERY timestep of the table (ldx_set_tables), by the same three skinny launches a forward would run on its B2 rows:
+// row t of d_emb_table is bit-identical to what those launches write for a sample whose timestep index is t (the skinny kernel's rows are independent).
+int Engine::build_emb_table() {
+    static const bool off = getenv("LDX_EMB_TABLE") && atoi(getenv("LDX_EMB_TABLE")) == 0;
+    if (off || d_emb_table || !d_temb || n_sigmas <= 0 || emb_total <= 0 || emb_total % 4) return LDX_OK;
+    const int mc = cfg.model_channels, ted = 4 * mc, n = n_sigmas;
+    float *e1 = nullptr, *e2 = nullptr, *tab = nullptr;
+    HIP_OK(hipMalloc((void**)&e1, (size_t)n * ted * 4));
+    HIP_OK(hipMalloc((void**)&e2, (size_t)n * ted * 4));
+    HIP_OK(hipMalloc((void**)&tab, (size_t)n * emb_total * 4));
+    launch_skinny(SkinnyArgs{d_temb, mc, te0.w, te0.b, e1, ted, n, ted, mc, 0, 1}, dt, nullptr);
+    launch_skinny(SkinnyArgs{e1, ted, te2.w, te2.b, e2, ted, n, ted, ted, 0, 1}, dt, nullptr);
+    launch_skinny(SkinnyArgs{e2, ted, emb_all.w, emb_all.b, tab, emb_total, n, emb_total, ted, 0, 0}, dt, nullptr);
+    HIP_OK(hipStreamSynchronize(nullptr));
+    HIP_OK(hipGetLastError());
+    (void)hipFree(e1); (void)hipFree(e2);
+    dev_allocs.push_back(tab);
+    d_emb_table = tab;
+    weight_bytes += (size_t)n * emb_total * 4;
+    return LDX_OK;
+}
+
+double Engine::steady_flops() const {
+    double f = flops;
+    if (ctx_cache) for (const Op& o : ops) if (o.ctx_only) f -= o.flops;
+    return f;
 }
 
 void Engine::plan_stash() {
@@ -968,6 +1009,7 @@ void Engine::plan_stash() {
     s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.ops = std::move(ops); s.flops = flops; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
+    s.kv_ptr = kv_ptr; s.kv_epoch = kv_epoch; s.g_ctxc = g_ctxc;
     s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB; s.g_cc = g_cc; s.g_ccn = g_ccn;
     s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
     s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
@@ -992,6 +1034,7 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc) {
         ops = std::move(s.ops); flops = s.flops; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
+        kv_ptr = s.kv_ptr; kv_epoch = s.kv_epoch; g_ctxc = s.g_ctxc;
         graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB; g_cc = s.g_cc; g_ccn = s.g_ccn;
         fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
         fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
@@ -1003,7 +1046,7 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc) {
     return false;
 }
 
-int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
+int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel) {
     if (op_end > ops.size()) op_end = ops.size();
     const bool prof_now = profiling && !prof_graph;
     if (prof_now && prof_events.size() < 2 * ops.size()) {
@@ -1013,6 +1056,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
     }
     for (size_t oi = op_begin; oi < op_end; ++oi) {
         const Op& o = ops[oi];
+        if ((ctx_sel == 1 && o.ctx_only) || (ctx_sel == 2 && !o.ctx_only)) continue;
         if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi], ls));
         switch (o.kind) {
             case OP_PREP: {
@@ -1022,6 +1066,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
                 p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
                 p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s; p.xB = b_xB;
                 p.cc = b_cc; p.Cx = cfg.in_channels - b_ccn;
+                if (kind == KIND_UNET && d_emb_table) { p.emb_table = d_emb_table; p.emb_n = emb_total; p.emb_out = d_emb_all; }
                 launch_prep(p, dt, ls);
             } break;
             case OP_CVT: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
@@ -1085,6 +1130,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end) {
         HIP_OK(hipStreamSynchronize(ls));
         for (size_t i = op_begin; i < op_end; ++i) {
             float ms = 0.f;
+            if ((ctx_sel == 1 && ops[i].ctx_only) || (ctx_sel == 2 && !ops[i].ctx_only)) continue;
             HIP_OK(hipEventElapsedTime(&ms, prof_events[2 * i], prof_events[2 * i + 1]));
             const Op& o = ops[i];
             std::string key = o.klabel[0] ? o.klabel : o.name;
@@ -1137,7 +1183,18 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
             if (rc) return rc;
         }
     }
-    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB && g_cc == c_concat && g_ccn == cc_channels);
+    // context cache: the ctx_only ops run here, eagerly, only when this plan's buffers do not hold the projections of (ctx, epoch) yet; every
+    // other op (and the captured graph) then leaves them out
+    const bool ctxc = ctx_cache;
+    b_ctx = ctx;
+    if (ctxc && !(kv_ptr == ctx && kv_epoch == ctx_epoch)) {
+        const bool pg = prof_graph; prof_graph = false;
+        const int rc = exec_ops(st, 0, (size_t)-1, 2);
+        prof_graph = pg;
+        if (rc) return rc;
+        kv_ptr = ctx; kv_epoch = ctx_epoch;
+    }
+    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB && g_cc == c_concat && g_ccn == cc_channels && g_ctxc == ctxc);
     // a captured graph has its pointers baked in: once a call arrives with other bindings (in ANY mode — the eager path below re-records
     // g_*), that graph must never be replayed against the new g_* (round 3: a stale graph was replayed after an eager call had moved g_*)
     if (!same) graph_valid = false;
@@ -1149,7 +1206,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     // capture only once the same (plan, pointers) have been run eagerly before: the first eager pass
     // also performs the one-time hipFuncSetAttribute calls, which are illegal during capture.
     const bool use_graph = graph_mode && warm && same;
-    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; g_cc = c_concat; g_ccn = cc_channels; warm = true;
+    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; g_cc = c_concat; g_ccn = cc_channels; g_ctxc = ctxc; warm = true;
     hipStream_t ls = st;
     if (use_graph) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -1160,7 +1217,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     }
     b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB; b_cc = c_concat; b_ccn = cc_channels;
     prof_graph = use_graph;
-    { int rc = exec_ops(ls); if (rc) return rc; }
+    { int rc = exec_ops(ls, 0, (size_t)-1, ctxc ? 1 : 0); if (rc) return rc; }
     if (use_graph) {
         hipGraph_t g = nullptr;
         HIP_OK(hipStreamEndCapture(cap_stream, &g));
@@ -1190,6 +1247,8 @@ std::string Engine::profile_json() const {
 int64_t Engine::n_launches() const {
     int64_t n = 0;
     for (const Op& o : ops) {
+        if (ctx_cache && o.ctx_only) continue;            // steady state of a sampling run: the context's projections are cached
+        if (o.kind == OP_ATTN && o.at.nsplit > 1) { n += 2; continue; }      // split keys + merge launch (attn512.hip)
         if (o.kind == OP_GN) n += o.gn.stats_chunks > GN_NCHUNK ? 2 : (o.gn.stats_chunks > 0 ? 1 : 2);      // fold + apply / apply / statistics + apply
         else n += (o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1 && !gemm_sk_fixup(o.g))) ? 2 : 1;
     }

@@ -49,6 +49,8 @@ struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb; RowGemmArgs rg;
     void* cvt_out; size_t cvt_n;
+    bool ctx_only = false;         // depends on the context alone (16-bit copy of ctx, the batched k|v projection): skipped while Engine::ctx_cache holds
+    bool emb_path = false;         // the time-embedding MLP / emb_layers launches: skipped when the per-timestep table exists (Engine::d_emb_table)
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;
     double flops; double bytes; char klabel[48];
@@ -57,7 +59,7 @@ struct ProfEntry { long count = 0; double ms = 0, flops = 0, bytes = 0; };
 
 struct EmbSrc { const HostTensor* w; const HostTensor* b; int n; };
 
-struct VaeAttnW { NormW norm; LinearW q, k, v, proj; };
+struct VaeAttnW { NormW norm; LinearW q, k, v, proj; LinearW qkv; /* C = 512: fused q | k | v projection [3C][C] for the flash kernel (attn512.hip); bias = [bq | bk | 0], bv folded into proj's */ };
 struct ClipLayerW { NormW ln1, ln2; LinearW qkv, out, fc1, fc2; };
 struct RdbW { LinearW c[5]; };
 struct T5LayerW { NormW ln1, ln2; LinearW qkv, o, wi, wo; };
@@ -122,6 +124,20 @@ public:
     // one CFG evaluation: x [B] is read by both halves of the [uncond; cond] batch (cond.py:186-226), sigma is one host scalar for every sample
     int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st);
     float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;
+    // ---- step-invariant work (round 5) ----
+    // (1) per-timestep table of the 22 emb_layers outputs: time_embed -> SiLU -> emb_layers is a pure function of the INTEGER timestep (a8: t = argmin
+    //     index; unet.py:333-342, ResBlock.py:283-295), so all n_sigmas rows are computed once by the SAME skinny kernels (bit-identical to the per-step
+    //     launches) and the prep kernel gathers the row: three launches per forward gone.  LDX_EMB_TABLE=0 keeps the per-step launches.
+    float* d_emb_table = nullptr;
+    int build_emb_table();
+    // (2) context cache (ldx_unet_context_cache): the caller promises that the bytes behind a ctx pointer do not change until it calls
+    //     ldx_unet_context_cache again; the 16-bit copy of ctx and the batched k|v projection of every cross-attention (transformer.py:186-245 recomputes
+    //     them every step only because a torch module has no notion of a sampling run) are then computed on the first evaluation of a (plan, ctx) only.
+    bool ctx_cache = false; uint64_t ctx_epoch = 1;
+    const void* kv_ptr = nullptr; uint64_t kv_epoch = 0;       // what the CURRENT plan's kvall buffer holds
+    bool g_ctxc = false;                                        // the captured graph was recorded without the ctx_only ops
+    int set_context_cache(int enable) { ctx_cache = enable != 0; ++ctx_epoch; return LDX_OK; }
+    double steady_flops() const;                                // algorithmic flops of one forward as executed in steady state (cached ops excluded)
     unsigned* d_sk_count = nullptr;                       // split-K tile counters (sk_counters()): one zeroed buffer per engine, every launch leaves it zeroed
     unsigned* sk_counters();
     int plan(int B2, int h, int w, int Mc);
@@ -158,7 +174,7 @@ private:
     bool mk_res(const std::string& pre, int Cin, int Cout, ResW& r);
     bool mk_xf(const std::string& pre, int C, int depth, XfW& x);
 
-    int exec_ops(hipStream_t ls, size_t op_begin = 0, size_t op_end = (size_t)-1);
+    int exec_ops(hipStream_t ls, size_t op_begin = 0, size_t op_end = (size_t)-1, int ctx_sel = 0);      // ctx_sel: 0 all ops, 1 skip ctx_only ops, 2 ONLY ctx_only ops
     // GroupNorm workspace: gn_ws_rows producer rows per image + GN_FOLD folded rows, x 32 groups x 2 floats (ldx_kernels.h gn_workspace_rows)
     int gn_ws_rows = 256;
     size_t gn_ws_bytes(int B, long HWmax) { gn_ws_rows = (int)gn_workspace_rows(HWmax); return (size_t)B * (gn_ws_rows + GN_FOLD) * 32 * 2 * 4; }
@@ -234,6 +250,7 @@ private:
         int B2 = 0, h = 0, w = 0, M = 0; std::vector<Op> ops; double flops = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
+        const void* kv_ptr = nullptr; uint64_t kv_epoch = 0; bool g_ctxc = false;
         const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0; const float* g_cc = nullptr; int g_ccn = 0;
         // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
         float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;

@@ -78,7 +78,17 @@ bool Engine::mk_vae_attn(const std::string& pre, int C, VaeAttnW& a) {
         for (int k = 0; k < C; ++k) acc += (double)wp->at(i * C + k) * (double)bv->at(k);
         return (float)acc;
     });
-    return a.proj.w && a.proj.b;
+    if (!a.proj.w || !a.proj.b) return false;
+    if (C == 512) {       // the flash kernel's operands: one [3C][C] projection, q | k | v rows as attention.hip's fused q|k|v (V row-major: no V^T GEMM)
+        const HostTensor *wq = get(pre + ".q.weight", {C, C, 1, 1}), *wk = get(pre + ".k.weight", {C, C, 1, 1}), *wv = get(pre + ".v.weight", {C, C, 1, 1});
+        const HostTensor *bq = get(pre + ".q.bias", {C}), *bk = get(pre + ".k.bias", {C});
+        if (!wq || !wk || !wv || !bq || !bk) return false;
+        a.qkv.N = 3 * C; a.qkv.K = C;
+        a.qkv.w = upload16((size_t)3 * C, C, [&](size_t r, size_t c) { const HostTensor* s = r < (size_t)C ? wq : (r < (size_t)2 * C ? wk : wv); return s->at((r % C) * C + c); });
+        a.qkv.b = upload32((size_t)3 * C, [&](size_t i) { return i < (size_t)C ? bq->at(i) : (i < (size_t)2 * C ? bk->at(i - C) : 0.f); });
+        if (!a.qkv.w || !a.qkv.b) return false;
+    }
+    return true;
 }
 
 int Engine::finalize_vae() {
@@ -162,6 +172,23 @@ void Engine::emit_vae_attn(const VaeAttnW& a, Act X, Act OUT, int B, int H, int 
     const int N = H * W, M = B * N, C = a.q.N;
     Act hn = new_act(M, C);
     op_gn("vae.attn.norm", X, hn, B, N, a.norm, 1e-6f, false);
+    {
+        // C = 512 (every SD VAE): flash attention, one head of D = 512 (attn512.hip) — q | k | v in one projection, the scores stay in the CUs.
+        // Before round 5 (and still for other widths / LDX_ATTN512=0): q k^T GEMM -> row softmax -> p v GEMM through HBM, below.
+        AttnArgs probe{}; probe.D = C; probe.B = B; probe.H = 1; probe.Nq = N; probe.Mk = N; probe.ldq = probe.ldk = probe.ldv = 3 * C; probe.ldo = C;
+        if (a.qkv.w && attn512_ok(probe)) {
+            Act qkv = new_act(M, 3 * C);
+            op_gemm("vae.attn.qkv", hn, a.qkv, qkv, Act{});
+            release(hn);
+            Act o = new_act(M, C);
+            const char* base = (const char*)ptr(qkv);
+            op_attn("vae.attn.flash", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, o, B, 1, N, N, C);
+            release(qkv);
+            op_gemm("vae.attn.proj", o, a.proj, OUT, X);
+            release(o);
+            return;
+        }
+    }
     Act q = new_act(M, C), k = new_act(M, C);
     op_gemm("vae.attn.q", hn, a.q, q, Act{});
     op_gemm("vae.attn.k", hn, a.k, k, Act{});

@@ -93,7 +93,11 @@ void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s)
 int gemm_choose_splitk(int M, int N, int K, bool geglu);   // 1 = no split
 constexpr int SK_FIXUP_MAX_S = 4;                          // in-kernel fix-up up to this many splits (the last arriver reads S slabs back to back); above: reduce launch
 constexpr int SK_COUNTERS = 8192;                          // per-tile counters a caller keeps for it
+#ifdef LDX_SK_FIXUP_BUILD
 inline size_t gemm_sk_ws_floats(int M, int N, int S) { return (size_t)S * ((size_t)M + 255) * ((size_t)N + 255); }      // slabs of whole tiles (tile <= 256 x 256), or the [S][M][N] layout
+#else
+inline size_t gemm_sk_ws_floats(int M, int N, int S) { return (size_t)S * (size_t)M * (size_t)N; }      // [S][M][N] fp32 partials for the reduce launch (the slab layout only exists in fix-up builds)
+#endif
 bool gemm_sk_fixup(const GemmArgs& a);                     // will launch_gemm(a) reduce inside the kernel?  (opt-in: LDX_SK_FIXUP=1; measured slower than the reduce launch)
 // 256-row ping-pong tiles (gemm_pp.hip; chosen by launch_gemm's cost model): bn = 128 / 160 / 256 tile width, lnf = GemmArgs::ln_c1 fold, S = K splits
 void launch_gemm_pp(const GemmArgs& a, int bn, bool lnf, int S, DType dt, hipStream_t s);
@@ -131,8 +135,15 @@ struct AttnArgs {
     // optional workspace of B * H * ceil(Mk / 64) floats (attn_pipe.hip, attn_pipe128.hip): with it the pipelined kernels prove most key blocks safe from the
     // norms of their keys (Cauchy-Schwarz) instead of taking the maximum of every score; null: the exact maximum on every block
     float* knorm_ws;
+    // D = 512 (attn512.hip, the VAE's single-head AttnBlock): the keys of a query block are split over `nsplit` workgroups when N / 128 query blocks
+    // alone would leave CUs idle; split_ws holds attn512_ws_floats() floats of per-split partial results (un-normalised O, running maximum,
+    // denominator) that a merge launch folds.  nsplit <= 1 or split_ws == null: one workgroup per query block, output written directly
+    float* split_ws; int nsplit;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+// launch_attention's dispatch switches (LDX_ATTN_PIPE, LDX_ATTN_PIPE128, LDX_ATTN_PIPE_MINWG, LDX_ATTN_PIPE_THR) are read once at load;
+// this re-reads them (tests / same-process A/B runs only — never on the launch path)
+void reload_dispatch_env();
 
 // Software-pipelined D = 40 kernel (attn_pipe.hip, round 4): attn_pipe_ok() says whether it takes the shape (D = 40, Nq % 256 == 0, Mk % 128 == 0,
 // Mk >= 256, no mask / bias); thr_override = NaN keeps the type's rescale threshold (tests force the rare path with small values).
@@ -140,6 +151,12 @@ bool attn_pipe_ok(const AttnArgs& a);
 void launch_attn_pipe(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 // The same pipeline for D = 128 (attn_pipe128.hip: Flux joint attention), 16-bit or MX fp8 output (AttnArgs::O8)
 bool attn_pipe128_ok(const AttnArgs& a);
+// Flash attention for D = 512 heads (attn512.hip): attn512_ok() says whether launch_attention takes the shape; the planner asks attn512_splits() for the
+// key split and provides attn512_ws_floats() floats of workspace in AttnArgs::split_ws
+bool attn512_ok(const AttnArgs& a);
+int attn512_splits(const AttnArgs& a);
+size_t attn512_ws_floats(const AttnArgs& a, int nsplit);
+void launch_attn512(const AttnArgs& a, DType dt, hipStream_t s);
 void launch_attn_knorm(const AttnArgs& a, DType dt, hipStream_t s);      // key-block norms for either pipelined kernel (AttnArgs::knorm_ws)
 void launch_attn_pipe128(const AttnArgs& a, DType dt, hipStream_t s, float thr_override);
 
@@ -229,6 +246,9 @@ struct PrepArgs {
     // c_concat (ModelBase.py:100-101: xc = cat((x / sqrt(sigma^2 + 1), c_concat), 1); inpainting UNets, in_channels = 9): x carries Cx channels,
     // channels Cx .. C - 1 come UNSCALED from cc [B][C - Cx][H][W].  cc == null: x carries all C channels (Cx is ignored)
     const float* cc; int Cx;
+    // emb_table != null: out_emb[b][0:emb_n) = emb_table[t][0:emb_n) — the row of the per-timestep table of every ResBlock's emb_layers output
+    // (Engine::build_emb_table): the time-embedding MLP is a pure function of the integer timestep, so it is evaluated once per timestep at load
+    const float* emb_table; int emb_n; float* emb_out;
 };
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s);
 // finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)

@@ -67,6 +67,11 @@ __global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
     int t = st;
     t = max(0, min(t, p.n_sigmas - 1));
     for (int j = tid; j < p.temb_dim; j += 256) p.temb_out[(long)b * p.temb_dim + j] = p.temb_table[(long)t * p.temb_dim + j];
+    if (p.emb_table) {                                   // emb_n % 4 == 0 (channel counts are multiples of 64)
+        const float4* src = (const float4*)(p.emb_table + (long)t * p.emb_n);
+        float4* dst = (float4*)(p.emb_out + (long)b * p.emb_n);
+        for (int j = tid; j < p.emb_n / 4; j += 256) dst[j] = src[j];
+    }
     if (tid == 0 && p.t_out) p.t_out[b] = (float)t;
 }
 

@@ -88,13 +88,29 @@ class UNetEngine:
     def set_graph_mode(self, on: bool):
         lib.check(self._lib.ldx_set_graph_mode(self._h, int(on)), "ldx_set_graph_mode")
 
+    def set_context_cache(self, on: bool = True):
+        """ldx_unet_context_cache: promise that a ctx buffer's contents stay put until the next call of this method (which invalidates the cache)."""
+        lib.check(self._lib.ldx_unet_context_cache(self._h, int(on)), "ldx_unet_context_cache")
+        self._ctx_cached = bool(on)
+
+    def invalidate_context(self):
+        """A cached context buffer was rewritten in place: drop its projections (the mode stays as it is)."""
+        self.set_context_cache(getattr(self, "_ctx_cached", False))
+
+    def _ctx_mode(self, cached: bool):
+        # every entry point states whether ITS ctx may be cached; the default is the reference's behaviour (recompute): a caller that hands over a
+        # fresh tensor per step (the hook) may get the address of the previous one back from the allocator, with other contents
+        if bool(cached) != getattr(self, "_ctx_cached", False):
+            self.set_context_cache(cached)
+
     def graph_stats(self):
         """(captures, replays) of the engine's hipGraph path since it was created."""
         c, r = C.c_int64(0), C.c_int64(0)
         lib.check(self._lib.ldx_graph_stats(self._h, C.byref(c), C.byref(r)), "ldx_graph_stats")
         return int(c.value), int(r.value)
 
-    def _run(self, fn, x, s, ctx, out):
+    def _run(self, fn, x, s, ctx, out, ctx_cached=False):
+        self._ctx_mode(ctx_cached)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
         b2, ch, h, w = x.shape
         assert ch == self.cfg.in_channels
@@ -108,11 +124,12 @@ class UNetEngine:
                      lib.current_stream_ptr()), fn.__name__)
         return out
 
-    def denoise(self, x, sigma, ctx, out=None, c_concat=None):
+    def denoise(self, x, sigma, ctx, out=None, c_concat=None, ctx_cached=False):
         """BaseModel.apply_model (ModelBase.py:72-133): x fp32 [B2,4,h,w], sigma [B2] (values), ctx [B2,M,768].
         c_concat [B2,in_channels-4,h,w] (inpainting UNets, ModelBase.py:100-101): appended unscaled behind the scaled x inside the engine's prep kernel."""
         if c_concat is None:
-            return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out)
+            return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out, ctx_cached)
+        self._ctx_mode(ctx_cached)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
         b2, ch, h, w = x.shape
         cc = c_concat.to(device=x.device, dtype=torch.float32).contiguous()
@@ -127,10 +144,11 @@ class UNetEngine:
                                                     lib.ptr(out), lib.current_stream_ptr()), "ldx_unet_denoise_concat")
         return out
 
-    def denoise_cfg(self, x, sigma: float, ctx, out=None):
+    def denoise_cfg(self, x, sigma: float, ctx, out=None, ctx_cached=False):
         """One CFG evaluation (calc_cond_batch, cond.py:186-226): x fp32 [B,4,h,w] is read by both halves of the [uncond x B; cond x B]
         batch, sigma is one scalar, ctx [2B,M,768]; returns [2B,4,h,w].  No torch kernel runs: the broadcast of x and sigma happens in
         the engine's own boundary kernels (ldx_unet_denoise_cfg)."""
+        self._ctx_mode(ctx_cached)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and x.is_contiguous(), "x must be a contiguous CUDA fp32 NCHW tensor"
         b, ch, h, w = x.shape
         assert ch == self.cfg.in_channels

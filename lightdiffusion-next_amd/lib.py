@@ -71,6 +71,8 @@ _SIGS = {
     "ldx_unet_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_denoise_cfg": (_i, [_vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_denoise_concat": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_context_cache": (_i, [_vp, _i]),
+    "ldx_reload_env": (_i, []),
     "ldx_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_plan_info": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),
     "ldx_profile": (_i, [_vp, _i, _i]),

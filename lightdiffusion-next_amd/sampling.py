@@ -14,6 +14,7 @@ Latents stay on the GPU in fp32; the per-step update runs in the HIP kernels beh
 ldx_bilinear.  Only Python scalars (sigmas) live on the host.
 """
 import math
+import os
 
 import numpy as np
 import torch
@@ -190,27 +191,42 @@ class CFGDenoiser:
         # Device buffers live with the ENGINE, keyed by shape, not with this object: a new sampling run (new CFGDenoiser, new latent and context
         # tensors) then presents the engine with the pointers of the previous run, and the hipGraph captured for the shape is replayed instead of
         # re-captured (measured on the reference-default multi-scale "euler": 2 captures + 2 eager evaluations of every 20 went away).
-        import os
         share = hasattr(engine, "__dict__") and os.environ.get("LDX_CFG_POOL", "1") != "0"      # 0: buffers private to this object (A/B switch)
         self._pool = engine.__dict__.setdefault("_ldx_cfg_pool", {}) if share else {}
         ctx = torch.cat(ctxs).contiguous()
-        key = ("ctx", tuple(ctx.shape))
+        key = ("ctx", tuple(ctx.shape), str(ctx.dtype), str(ctx.device))
         if key not in self._pool:
             self._pool[key] = torch.empty_like(ctx)
-        self._pool[key].copy_(ctx)
         self.ctx = self._pool[key]
         # the shared context buffer holds THIS object's context only while it is the owner: another CFGDenoiser of the same shape on the same engine
-        # (created later, used in between) overwrites it, and __call__ then restores it from the private copy
+        # (created later, used in between) overwrites it, and __call__ then restores it from the private copy.  The owner is held through a weak
+        # reference: the pool must not keep a finished run's denoiser (and its private context copy) alive.
         self._ctx_src, self._ctx_key = ctx, ("ctx_owner",) + key[1:]
-        self._pool[self._ctx_key] = self
+        self._take_context()
         self.sides = sides                                  # cond_or_uncond of the batch
         self.n_entries = len(sides)
         self.nb = self.n_entries * batch
         self.batch = batch
         self.simple = (not self.skip_uncond) and sides == [1, 0]
+        # this object's context lives in an engine-lifetime buffer that only _take_context() writes: its k|v projections may be cached across steps
+        self._kw = {"ctx_cached": os.environ.get("LDX_CTX_CACHE", "1") != "0"} if hasattr(engine, "invalidate_context") else {}      # 0: recompute per call (A/B switch)
+
+    def _take_context(self):
+        """Write this object's context into the engine's buffer and become its owner.  The engine caches the context's k|v projections per buffer
+        (ldx_unet_context_cache: to_k / to_v of all cross-attentions are functions of the context alone — Attention.py:100-124 recomputes them every
+        step); every rewrite of the buffer goes through here, so it also drops that cache."""
+        import weakref
+        self.ctx.copy_(self._ctx_src)
+        self._pool[self._ctx_key] = weakref.ref(self)
+        if hasattr(self.engine, "invalidate_context"):
+            self.engine.invalidate_context()
+
+    def _owns_context(self):
+        ref = self._pool.get(self._ctx_key)
+        return ref is not None and ref() is self
 
     def _buffers(self, shape):
-        key = ("bufs", self.nb, tuple(shape))
+        key = ("bufs", self.nb, tuple(shape), str(self.ctx.device))
         if key not in self._pool:
             b, c, h, w = shape
             dev = self.engine.device
@@ -234,9 +250,8 @@ class CFGDenoiser:
     def __call__(self, x, sigma):
         """Returns (denoised_uncond, denoised_cond), each [B,4,h,w] fp32."""
         xin, sig, out, xstage = self._buffers(x.shape)
-        if self._pool.get(self._ctx_key) is not self:
-            self.ctx.copy_(self._ctx_src)
-            self._pool[self._ctx_key] = self
+        if not self._owns_context():
+            self._take_context()
         b = self.batch
         if self.simple and hasattr(self.engine, "denoise_cfg") and x.is_cuda and x.dtype == torch.float32:
             # [uncond; cond] batch built INSIDE the engine (ldx_unet_denoise_cfg).  The engine's captured graph is tied to the pointers it was
@@ -244,12 +259,12 @@ class CFGDenoiser:
             # sampling run): x always goes through the engine-lifetime staging tensor of its shape (one 256 KiB device copy per evaluation).
             xstage.copy_(x)
             x = xstage
-            self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out)
+            self.engine.denoise_cfg(x, float(sigma), self.ctx, out=out, **self._kw)
             return out[:b], out[b:]
         for i in range(self.n_entries):                     # the general case (cfg 1 / several entries per side): host-side batch assembly
             xin[i * b:(i + 1) * b].copy_(x)
         sig.fill_(float(sigma))
-        self.engine.denoise(xin, sig, self.ctx, out=out)
+        self.engine.denoise(xin, sig, self.ctx, out=out, **self._kw)
         cond = self._side(out, 0)
         if self.skip_uncond:
             return cond, cond

@@ -2,7 +2,7 @@
 
 Reference op: F.scaled_dot_product_attention without mask (Attention/AttentionMethods.py:107-150, called by CrossAttention.forward
 Attention.py:100-124).  The kernel is compared with fp64 / fp32 torch on the same 16-bit inputs and with the kernels it replaces
-(attn32*, LDX_ATTN_PIPE=0); the dispatcher reads LDX_ATTN_PIPE / LDX_ATTN_PIPE_MINWG / LDX_ATTN_PIPE_THR per call, so one process runs all of them.
+(attn32*, LDX_ATTN_PIPE=0); the dispatcher reads LDX_ATTN_PIPE / LDX_ATTN_PIPE_MINWG / LDX_ATTN_PIPE_THR once at load; `_Env` re-reads them through ldx_reload_env(), so one process runs all of them.
 
 What is specific to this kernel and therefore tested here:
   * the lazy integer reference maximum: results must not depend on the rescale threshold (THR = 0 / 3 / default agree to rounding: a rescale
@@ -46,6 +46,12 @@ class _Env:
     def __init__(self, **kw):
         self.kw = {k: (None if v is None else str(v)) for k, v in kw.items()}
 
+    @staticmethod
+    def _reload():
+        # the library reads its dispatch switches once at load (no getenv on the launch path); a test that flips them re-reads them explicitly
+        import ldx_amd
+        ldx_amd.lib.check(ldx_amd.lib.load().ldx_reload_env(), "ldx_reload_env")
+
     def __enter__(self):
         self.old = {k: os.environ.get(k) for k in self.kw}
         for k, v in self.kw.items():
@@ -53,6 +59,7 @@ class _Env:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        self._reload()
 
     def __exit__(self, *a):
         for k, v in self.old.items():
@@ -60,6 +67,7 @@ class _Env:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+        self._reload()
 
 
 def _attn(L, ldx, q, k, v, H, scale, code, pipe, thr=None):

@@ -74,7 +74,7 @@ def test_ksampler_full_width_vs_reference(full, ldx, dt, tol):
 
 
 @pytest.mark.parametrize("lat", [64, 128])
-@pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])
+@pytest.mark.parametrize("dt,tol", [("f16", 5e-3), ("bf16", 3e-2)])       # measured 2.0e-3 / 1.8e-2 at both sizes (round 5): tighter than the generic 1e-2 / 5e-2
 def test_ksampler_20_steps_full_width_vs_reference(full, ldx, golden_dir, lat, dt, tol):
     """BASELINE configs 1 (512^2) and 2 (1024^2 = the headline bench.py times) END TO END: 20 sample_euler / normal steps, cfg 7, seed 42, multiscale
     off, against the reference's own KSampler.sample latents (tests/golden/unet_full20.npz from oracle/ref_capture_full20.py).  bench.py's

@@ -25,6 +25,17 @@ def test_op_tests_on_forced_pingpong_tiles(ldx_lib, tile):
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
 
 
+def test_op_tests_on_the_forced_64x160_tile(ldx_lib):
+    """Round 5: the 64 x 160 register-staged tile (opt-in LDX_TILE64X160=1: measured slower than 64 x 64 on the 32^2 level's projections, kept
+    for the record) on the GEMM op tests — ragged M / N / K, bias / residual / rowvec epilogues, split-K; convs and GEGLU fall back to their own tiles."""
+    env = dict(os.environ, LDX_GEMM_TILE="64160")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_ops_gpu.py", "tests/test_rowgemm_gpu.py", "-k", "test_gemm or rowgemm"],
+                       cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    tail = r.stdout[-1500:]
+    print(tail, r.stderr[-500:])
+    assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
 def test_large_shapes_pick_the_pingpong_kernel_and_match_torch(ldx, ldx_lib):
     """Un-forced: shapes the cost model sends to the ping-pong kernel (plain GEMM with long K, 3x3 conv at the level-0 size), against
     torch fp32 on the same 16-bit operands."""

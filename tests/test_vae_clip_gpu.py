@@ -139,7 +139,8 @@ def test_clip_pooled_and_text_projection_in_engine(ldx):
 
 
 def test_vae_attention_query_chunks_match_one_chunk(ldx, ldx_lib):
-    """The mid-block attention runs over query-row chunks (engine_models.cpp emit_vae_attn; a 2048^2 decode no longer holds an 8 GiB score matrix).
+    """(The GEMM -> softmax -> GEMM path, kept for mid-block widths other than 512 and as LDX_ATTN512=0; at C = 512 the flash kernel of round 5 took over.)
+    The mid-block attention runs over query-row chunks (engine_models.cpp emit_vae_attn; a 2048^2 decode no longer holds an 8 GiB score matrix).
     LDX_VAE_ATTN_CHUNK_MIB is read once per process, so the chunked decode (1 MiB chunks -> 16 chunks of 256 rows at latent 64^2) runs in a
     subprocess and is compared with this process' one-chunk decode of the same latent."""
     import subprocess, sys, os, tempfile
@@ -155,7 +156,7 @@ def test_vae_attention_query_chunks_match_one_chunk(ldx, ldx_lib):
                 "vae = ldx.VAEDecoderEngine(cfg, sd, device=0, dtype='bf16')\n"
                 "z = torch.randn(1, 4, 64, 64, generator=torch.Generator().manual_seed(4))\n"
                 f"torch.save(vae.decode(z.cuda()).cpu(), {os.path.join(d, 'o.pt')!r}); print('launches', vae.plan_info()['launches'])\n")
-        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LDX_VAE_ATTN_CHUNK_MIB="1"), capture_output=True, text=True, timeout=600)
+        r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LDX_VAE_ATTN_CHUNK_MIB="1", LDX_ATTN512="0"), capture_output=True, text=True, timeout=600)
         assert r.returncode == 0, r.stderr[-1500:]
         chunked = torch.load(os.path.join(d, "o.pt"))
     n1 = vae.plan_info()["launches"]
