@@ -546,15 +546,10 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
     // Long-K problems (3x3 convs) keep the big tile: measured 112 us (128x128) vs 125 us (64x64) at 64^2, 640->640;
     // 2048x1280x1280 went 27.6 -> 18.8 us with 64x64.
     if (tiles < 400 && K <= 24 * BK) {
-        // 64 x 160 tiles (round 5, opt-in LDX_TILE64X160=1): 45.7 flop per operand byte instead of 32 and ONE round of 256 workgroups for the SD1.5
-        // 32^2 level's 25 N = K = 1280 projections — measured SLOWER, 25.6 vs 22.8 us per launch, step 14.20 -> 14.29 ms same box
-        // (profiles/r05/ab_caches_tile64x160.txt): with one 4-wave workgroup per CU and one K-tile of register-staged loads in flight the launch is bound
-        // by the latency of each K-tile's loads, which 2.5 co-resident 64 x 64 workgroups hide and a single 64 x 160 one does not.
-        static const bool t64x160 = getenv("LDX_TILE64X160") && atoi(getenv("LDX_TILE64X160")) != 0;
-        if (plain && t64x160 && N % 160 == 0 && splitk <= 1) {
-            const long t = (long)((M + 63) / 64) * (N / 160);
-            if (t >= 192 && t <= 512) return {64, 160};
-        }
+        // Round 5: where a 64 x 160 tiling still gives every CU work, the LDS-DMA ring kernel (gemm_ring.hip: 45.7 instead of 32 flop per operand byte AND
+        // three to four K-tiles in flight) takes the launch.  (The same tile on THIS kernel's register-staged loop measured slower than 64 x 64: 25.6 vs
+        // 22.8 us at 2048 x 1280 x 1280 — one K-tile in flight per CU; profiles/r05/ab_caches_tile64x160.txt.)
+        if (gemm_ring_ok(M, N, K, plain, splitk)) return {64, 160};
         return {64, 64};
     }
     return {128, bn};
@@ -627,7 +622,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
     else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
     else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);
     else if (a.geglu && t.bm == 64) launch_gemm_inst<T, MODE, 128, 128>(a, S, s);      // (forced tiles only) the GEGLU pairing needs 64-column wave tiles
-    else if (MODE == 0 && t.bm == 64 && t.bn == 160) { if constexpr (MODE == 0) launch_gemm_inst<T, 0, 64, 160>(a, S, s); }
+    else if (MODE == 0 && t.bm == 64 && t.bn == 160 && S == 1 && a.K % BK == 0) launch_gemm_ring(a, DTypeOf<T>::v, s);      // gemm_ring.hip
     else if (t.bm == 64) launch_gemm_inst<T, MODE, 64, 64>(a, S, s);
     else if (t.bn == 160) launch_gemm_inst<T, MODE, 128, 160>(a, S, s);
     else launch_gemm_inst<T, MODE, 128, 128>(a, S, s);

@@ -12,6 +12,9 @@ template <> struct DTypeOf<__bf16> { static constexpr DType v = DT_BF16; };
 template <> struct DTypeOf<_Float16> { static constexpr DType v = DT_F16; };
 
 constexpr int BK = 64;
+// gemm_ring.hip: 64 x 160 LDS-DMA ring tiles for mid-size plain GEMMs; gemm_tile (gemm.hip) asks gemm_ring_ok
+bool gemm_ring_ok(int M, int N, int K, bool plain, int splitk);
+void launch_gemm_ring(const GemmArgs& a, DType dt, hipStream_t s);
 // BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
 // 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)
 // that N = 320 / 960 / 1920 get with 128.

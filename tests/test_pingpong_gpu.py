@@ -25,15 +25,58 @@ def test_op_tests_on_forced_pingpong_tiles(ldx_lib, tile):
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
 
 
-def test_op_tests_on_the_forced_64x160_tile(ldx_lib):
-    """Round 5: the 64 x 160 register-staged tile (opt-in LDX_TILE64X160=1: measured slower than 64 x 64 on the 32^2 level's projections, kept
-    for the record) on the GEMM op tests — ragged M / N / K, bias / residual / rowvec epilogues, split-K; convs and GEGLU fall back to their own tiles."""
+def test_op_tests_on_the_forced_ring_tile(ldx_lib):
+    """Round 5: the 64 x 160 LDS-DMA ring kernel (csrc/gemm_ring.hip; plain GEMMs of the 32^2 level: 2048 x 1280 x 1280 in one round of 256 workgroups,
+    three to four K-tiles in flight) forced onto the GEMM op tests — ragged M / N, bias / residual / rowvec / fp32-output epilogues, GroupNorm statistics;
+    split-K, ragged K, convs and GEGLU fall back to their own tiles."""
     env = dict(os.environ, LDX_GEMM_TILE="64160")
     r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "tests/test_ops_gpu.py", "tests/test_rowgemm_gpu.py", "-k", "test_gemm or rowgemm"],
                        cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     tail = r.stdout[-1500:]
     print(tail, r.stderr[-500:])
     assert r.returncode == 0 and " passed" in tail and "failed" not in tail, tail
+
+
+@pytest.mark.parametrize("shape", [(2048, 1280, 1280), (2048, 3840, 1280), (2000, 1280, 640), (8192, 640, 2560)])
+def test_ring_gemm_shapes_match_torch(ldx_lib, shape):
+    """Un-forced: shapes the planner sends to the ring kernel (M 2048, N = K = 1280: the SD1.5 32^2 level's proj_in / to_out / to_q / proj_out) and, with
+    LDX_GEMM_TILE unset, whatever it picks for the others — bias + residual epilogue against torch fp32 on the same bf16 operands, bit-identical repeats,
+    K-tile counts below / at / above the ring depth."""
+    import ctypes as C
+    import torch
+    L = ldx_lib
+    p = lambda t: C.c_void_p(t.data_ptr())
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    M, N, K = shape
+    g = torch.Generator(device="cuda").manual_seed(M + N + K)
+    A = torch.randn(M, K, device="cuda", generator=g).bfloat16(); W = (torch.randn(N, K, device="cuda", generator=g) / K ** 0.5).bfloat16()
+    bias = torch.randn(N, device="cuda", generator=g); R = torch.randn(M, N, device="cuda", generator=g).bfloat16()
+    outs = []
+    for _ in range(2):
+        Cc = torch.full((M, N), float("nan"), device="cuda", dtype=torch.bfloat16)
+        assert L.ldx_op_gemm(p(A), K, p(W), M, N, K, p(bias), None, 0, 1, 0, p(R), N, p(Cc), N, None, 0, 0, st) == 0
+        outs.append(Cc)
+    torch.cuda.synchronize()
+    ref = A.float() @ W.float().t() + bias + R.float()
+    rel = float((outs[0].float() - ref).norm() / ref.norm())
+    print(f"gemm {shape}: rel-L2 {rel:.3e}")
+    assert rel < 4e-3
+    assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.parametrize("K", [128, 192, 256, 320, 384])
+def test_ring_gemm_short_k(ldx_lib, K):
+    """K-tile counts 2 .. 6 around the ring depth of five (prologue / tail vmcnt cases), forced onto the ring tile through LDX_GEMM_TILE in a subprocess."""
+    code = (f"import sys, ctypes as C, torch; sys.path.insert(0, {ROOT!r}); import ldx_amd as ldx; L = ldx.lib.load()\n"
+            "p = lambda t: C.c_void_p(t.data_ptr()); st = C.c_void_p(torch.cuda.current_stream().cuda_stream)\n"
+            f"M, N, K = 1000, 480, {K}\n"
+            "g = torch.Generator(device='cuda').manual_seed(K)\n"
+            "A = torch.randn(M, K, device='cuda', generator=g).bfloat16(); W = (torch.randn(N, K, device='cuda', generator=g) / K ** 0.5).bfloat16()\n"
+            "Cc = torch.full((M, N), float('nan'), device='cuda', dtype=torch.bfloat16)\n"
+            "assert L.ldx_op_gemm(p(A), K, p(W), M, N, K, None, None, 0, 1, 0, None, 0, p(Cc), N, None, 0, 0, st) == 0\n"
+            "ref = A.float() @ W.float().t(); rel = float((Cc.float() - ref).norm() / ref.norm()); print('REL', rel); assert rel < 4e-3\n")
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, LDX_GEMM_TILE="64160"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "REL" in r.stdout, (r.stdout[-500:], r.stderr[-1500:])
 
 
 def test_large_shapes_pick_the_pingpong_kernel_and_match_torch(ldx, ldx_lib):
