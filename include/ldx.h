@@ -237,7 +237,10 @@ int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses);
  * blocks run the block-scaled 16x16x128 MFMA on e4m3fn operands with one E8M0 scale per 32 consecutive k (weights
  * quantised once in ldx_finalize, activations per forward); everything else stays 16-bit.  Call before ldx_finalize;
  * needs hidden_size % 128 == 0 and mlp_hidden % 128 == 0.  The reference runs Flux from Q8_0 weights (also 32-element
- * blocks, src/Quantize/Quantizer.py:94-112) dequantised to 16-bit, i.e. W8A16; this mode is W8A8. */
+ * blocks, src/Quantize/Quantizer.py:94-112) dequantised to 16-bit, i.e. W8A16; this mode is W8A8.
+ * enable = 1 (round 5): ... and, at head dim 128, QK^T and PV of the joint attention on the block-scaled 32x32x64 MFMA as well (the rule of
+ * ldx_op_attention_fp8 below: Q / K quantised by the QKNorm + RoPE kernel, V by a transposing quantiser, P rounded to e4m3) — the whole block is fp8 MFMA.
+ * enable = 2: the linears only; attention stays 16-bit (what "fp8" meant through round 4; kept for A/B runs). */
 int ldx_flux_set_fp8(ldx_engine* e, int enable);
 
 /* ---- T5-XXL text encoder (Flux conditioning) ---------------------------------------------------- */
@@ -298,6 +301,21 @@ int ldx_op_gemm(const void* A, int lda, const void* W, int M, int N, int K, cons
 /* LayerNorm whose output is quantised as ldx_op_mx_quant would quantise the 16-bit Y (C % 128 == 0). */
 int ldx_op_layernorm_mx(const void* X, int ldx, int rows, int C, float eps, const float* gamma, const float* beta,
                         void* Y8, int ldy8, void* S8, int s8_ld, int dtype, void* stream);
+/* ---- MX fp8 attention for head dim 128 (csrc/attn_mx.hip; round 5: the Flux "fp8 MFMA" mode of BASELINE config 4 with QK^T and PV on the block-scaled
+ * 32x32x64 MFMA instead of 16-bit).  No reference counterpart (BlackForest/Flux.py:18-33 runs SDPA in 16 bit): pinned by the stated rule only.
+ *   Q, K: ldx_op_mx_quant's format on the [rows][H * 128] matrix — e4m3 bytes, one E8M0 scale per (row, head, 32 consecutive d), scale dwords [H][s_ld]
+ *         (byte j of dword [h][row] = d block j).  ldx_op_qk_norm_rope_mx produces them from the fused q|k|v projection in one pass (QKNorm + RoPE +
+ *         quantiser), bit-identical to the 16-bit rope followed by ldx_op_mx_quant.
+ *   V:    ldx_op_mx_vt_quant — transposed, V8T [B][H][128 d][Lp] with Lp = L rounded up to 128, one scale per (d, 32 consecutive keys) in
+ *         SV [B][H][Lp / 128][128 d] dwords (byte t = keys 32 t .. 32 t + 31 of that 128-key block); inside every 64-key step the bytes are in the MFMA's
+ *         contraction order: byte k holds key 32 (k >> 5) + 8 ((k & 15) >> 2) + 4 ((k >> 4) & 1) + (k & 3).
+ *   P:    2^(s c - m) with m = ceil of the scaled row maximum, updated lazily (an integer exponent: P <= 4), rounded to e4m3 at the fixed scale 2^-6; the row sums add the ROUNDED values (an all-ones row of V^T).
+ * Output: 16-bit O [rows][ldo] (O8 == NULL) or MX fp8 O8 / SO as ldx_op_attention_mx writes them. */
+int ldx_op_qk_norm_rope_mx(const void* QKV, int ld, int rows, int L, int H, const float* qscale, const float* kscale, const float* cosT, const float* sinT, float eps,
+                           void* Q8, void* K8, int ld8, void* SQ, void* SK, int s_ld, int dtype, void* stream);
+int ldx_op_mx_vt_quant(const void* V, int ldv, int B, int H, int L, void* V8T, void* SV, int Lp, int dtype, void* stream);
+int ldx_op_attention_fp8(const void* Q8, int ldq8, const void* SQ, int sq_ld, const void* K8, int ldk8, const void* SK, int sk_ld, const void* V8T, const void* SV, int Lp,
+                         void* O, int ldo, void* O8, int ldo8, void* SO, int so_ld, int B, int H, int Nq, int Mk, float scale, int dtype, void* stream);
 /* Attention (head dim 128, no mask) whose output is quantised in the epilogue exactly as ldx_op_mx_quant would quantise the
  * 16-bit O [B*Nq][H*128]: O8 bytes (row stride ldo8) + scales uint32 [H][so_ld] (one word per row and head).  Needs
  * B * H * ceil(Nq / 128) >= 16 workgroups (smaller problems: ldx_op_attention + ldx_op_mx_quant). */

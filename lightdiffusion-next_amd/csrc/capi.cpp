@@ -186,6 +186,7 @@ int ldx_flux_set_fp8(ldx_engine* e, int enable) {
     if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_set_fp8: not a Flux engine"); return LDX_EINVAL; }
     if (e->impl->finalized) { set_error("ldx_flux_set_fp8: call before ldx_finalize (the weights are quantised there)"); return LDX_ESTATE; }
     e->impl->fx_fp8 = enable != 0;
+    e->impl->fx_fp8_attn = enable == 1;        // 1: linears AND attention; 2: linears only (the round-2 .. 4 behaviour: QK^T / PV stay 16-bit)
     return LDX_OK;
     GUARD_END
 }
@@ -371,6 +372,32 @@ int ldx_op_attention_mx(const void* Q, int ldq, const void* K, int ldk, const vo
     if (!attention_mx_out_ok(a)) { set_error("ldx_op_attention_mx: needs head dim 128 and at least 16 query blocks of 128 (B * H * ceil(Nq / 128))"); return LDX_EINVAL; }
     launch_attention(a, dtype_of(dtype), (hipStream_t)stream);
     return check_launch("ldx_op_attention_mx");
+}
+int ldx_op_mx_vt_quant(const void* V, int ldv, int B, int H, int L, void* V8T, void* SV, int Lp, int dtype, void* stream) {
+    if (!V || !V8T || !SV || B <= 0 || H <= 0 || L <= 0 || ldv % 8 || Lp % 128 || Lp < L) { set_error("ldx_op_mx_vt_quant: bad argument (ldv % 8, Lp % 128 == 0, Lp >= L)"); return LDX_EINVAL; }
+    MxVtArgs a{V, ldv, B, H, L, V8T, (uint32_t*)SV, Lp};
+    launch_mx_vt_quant(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_mx_vt_quant");
+}
+int ldx_op_attention_fp8(const void* Q8, int ldq8, const void* SQ, int sq_ld, const void* K8, int ldk8, const void* SK, int sk_ld, const void* V8T, const void* SV, int Lp,
+                         void* O, int ldo, void* O8, int ldo8, void* SO, int so_ld, int B, int H, int Nq, int Mk, float scale, int dtype, void* stream) {
+    AttnMxArgs a{};
+    a.Q8 = Q8; a.ldq8 = ldq8; a.SQ = (const uint32_t*)SQ; a.sq_ld = sq_ld; a.K8 = K8; a.ldk8 = ldk8; a.SK = (const uint32_t*)SK; a.sk_ld = sk_ld;
+    a.V8T = V8T; a.SV = (const uint32_t*)SV; a.Lp = Lp; a.O = O; a.ldo = ldo; a.O8 = O8; a.ldo8 = ldo8; a.SO = (uint32_t*)SO; a.so_ld = so_ld;
+    a.B = B; a.H = H; a.Nq = Nq; a.Mk = Mk; a.scale = scale;
+    if (!attn_mx_ok(a) || sq_ld < B * Nq || sk_ld < B * Mk) { set_error("ldx_op_attention_fp8: bad argument (head dim 128; ld % 16; Lp % 128 == 0, Lp >= Mk; scale strides >= rows)"); return LDX_EINVAL; }
+    launch_attn_mx(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_attention_fp8");
+}
+int ldx_op_qk_norm_rope_mx(const void* QKV, int ld, int rows, int L, int H, const float* qscale, const float* kscale, const float* cosT, const float* sinT, float eps,
+                           void* Q8, void* K8, int ld8, void* SQ, void* SK, int s_ld, int dtype, void* stream) {
+    if (!QKV || !qscale || !kscale || !cosT || !sinT || !Q8 || !K8 || !SQ || !SK || rows <= 0 || L <= 0 || H <= 0 || ld % 8 || ld8 % 16 || ld8 < H * 128 || s_ld < rows) {
+        set_error("ldx_op_qk_norm_rope_mx: bad argument (head dim 128; ld % 8, ld8 % 16, s_ld >= rows)"); return LDX_EINVAL; }
+    QkRopeArgs a{};
+    a.QKV = (void*)QKV; a.ld = ld; a.rows = rows; a.L = L; a.H = H; a.D = 128; a.qscale = qscale; a.kscale = kscale; a.cosT = cosT; a.sinT = sinT; a.eps = eps;
+    a.Q8 = Q8; a.K8 = K8; a.ld8 = ld8; a.SQ = (uint32_t*)SQ; a.SK = (uint32_t*)SK; a.s8_ld = s_ld; a.row8 = 0;
+    launch_qk_norm_rope_mx(a, dtype_of(dtype), (hipStream_t)stream);
+    return check_launch("ldx_op_qk_norm_rope_mx");
 }
 int ldx_op_mx_quant(const void* X, int ldx_, int rows, int K, void* Y, int ldy, void* scales, int scales_ld, int dtype, void* stream) {
     if (!X || !Y || !scales || rows <= 0 || K <= 0 || K % 128 || ldx_ % 8 || ldy % 16 || ldy < K || scales_ld < rows) {

@@ -1090,6 +1090,8 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
                 }
             } break;
             case OP_MXQ: launch_mx_quant(o.mq, dt, ls); break;
+            case OP_ATTN_MX: launch_attn_mx(o.am, dt, ls); break;
+            case OP_MXVT: launch_mx_vt_quant(o.vt, dt, ls); break;
             case OP_GEMM2: launch_gemm2(o.g, o.g2, dt, ls); break;
             case OP_XATTN: launch_xattn_block(o.xa, dt, ls); break;
             case OP_FFBLOCK: launch_ff_block(o.fb, dt, ls); break;
@@ -1121,7 +1123,8 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
             case OP_FX_CVT_CTX: launch_f32_to_t(b_ctx, o.cvt_out, o.cvt_n, dt, ls); break;
             case OP_FX_SKINNY_Y: { SkinnyArgs a = o.sk; a.x = b_y; launch_skinny(a, dt, ls); } break;
             case OP_FX_SKINNY_G: break;
-            case OP_FX_ROPE: { QkRopeArgs a = o.rp; const int hp = a.D / 2; a.cosT = b_cos + (size_t)o.i0 * hp; a.sinT = b_sin + (size_t)o.i0 * hp; launch_qk_norm_rope(a, dt, ls); } break;
+            case OP_FX_ROPE: { QkRopeArgs a = o.rp; const int hp = a.D / 2; a.cosT = b_cos + (size_t)o.i0 * hp; a.sinT = b_sin + (size_t)o.i0 * hp;
+                               if (a.Q8) launch_qk_norm_rope_mx(a, dt, ls); else launch_qk_norm_rope(a, dt, ls); } break;
             case OP_FX_UNPATCH: launch_flux_unpatchify(fx_tok, 4 * o.i1, b_den ? b_x : nullptr, b_s, b_out, o.i0, o.i1, o.i2, o.i3, ls); break;
         }
         if (prof_now) HIP_OK(hipEventRecord(prof_events[2 * oi + 1], ls));
@@ -1138,6 +1141,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
                 char sh[96] = "";
                 if (o.kind == OP_GEMM) snprintf(sh, sizeof(sh), " M%d N%d K%d sk%d%s", o.g.M, o.g.N, o.g.K, o.g.splitk, o.g.geglu ? " geglu" : "");
                 else if (o.kind == OP_ATTN) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D%d", o.at.B, o.at.H, o.at.Nq, o.at.Mk, o.at.D);
+                else if (o.kind == OP_ATTN_MX) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D128", o.am.B, o.am.H, o.am.Nq, o.am.Mk);
                 else if (o.kind == OP_GN) snprintf(sh, sizeof(sh), " B%d HW%d C%d", o.gn.B, o.gn.HW, o.gn.C);
                 else if (o.kind == OP_LN) snprintf(sh, sizeof(sh), " R%d C%d", o.ln.rows, o.ln.C);
                 else if (o.kind == OP_MXQ) snprintf(sh, sizeof(sh), " R%d K%d", o.mq.rows, o.mq.K);

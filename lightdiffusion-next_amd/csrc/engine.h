@@ -43,11 +43,11 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
-              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK, OP_ROWGEMM };
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK, OP_ROWGEMM, OP_ATTN_MX, OP_MXVT };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
-    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb; RowGemmArgs rg;
+    GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb; RowGemmArgs rg; AttnMxArgs am; MxVtArgs vt;
     void* cvt_out; size_t cvt_n;
     bool ctx_only = false;         // depends on the context alone (16-bit copy of ctx, the batched k|v projection): skipped while Engine::ctx_cache holds
     bool emb_path = false;         // the time-embedding MLP / emb_layers launches: skipped when the per-timestep table exists (Engine::d_emb_table)
@@ -96,6 +96,7 @@ public:
     void fb_reset() { fb_have_first = fb_have_res = false; fb_prev_valid = false; }
     // MX fp8 mode (BASELINE config 4 "fp8 MFMA"): the block linears run on block-scaled fp8 operands; opt-in, own parity class
     bool fx_fp8 = false;
+    bool fx_fp8_attn = false;        // ... and QK^T / PV of the joint attention on MX fp8 too (attn_mx.hip; ldx_flux_set_fp8 mode 1, head dim 128)
     bool mx_quantize_weight(LinearW& w);
     int plan_flux(int B, int h, int w, int Lt);
     int run_flux(const float* x, const float* sigma, const float* ctx, const float* y, const float* guidance,

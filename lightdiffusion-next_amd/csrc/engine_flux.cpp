@@ -213,10 +213,31 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             ops.push_back(o);
             return fused;
         };
-        auto rope = [&](const char* name, Act QKV, const float* qs, const float* ks, int tok0) {
+        // MX fp8 attention (ldx_flux_set_fp8 mode 1, head dim 128; attn_mx.hip): the QKNorm + RoPE op writes q / k as MX fp8 (+ one scale dword per (row, head)) instead
+        // of 16 bit, a transposing quantiser turns v into V^T bytes in the MFMA's key order, and the attention op runs both products on the block-scaled MFMA.
+        static const bool attn8_env = !(getenv("LDX_FLUX_FP8_ATTN") && atoi(getenv("LDX_FLUX_FP8_ATTN")) == 0);      // A/B switch
+        const bool attn8 = fx_fp8 && fx_fp8_attn && attn8_env && D == 128;
+        const int Lp = (L + 127) / 128 * 128;
+        char *a8_q = nullptr, *a8_k = nullptr, *a8_vt = nullptr; uint32_t *a8_sq = nullptr, *a8_sk = nullptr, *a8_sv = nullptr;
+        if (attn8) {
+            auto al = [&](size_t bytes) { return (char*)arena + a_alloc(bytes); };
+            a8_q = al((size_t)RT * C); a8_k = al((size_t)RT * C); a8_vt = al((size_t)B * H * 128 * Lp);
+            a8_sq = (uint32_t*)al((size_t)H * RT * 4); a8_sk = (uint32_t*)al((size_t)H * RT * 4); a8_sv = (uint32_t*)al((size_t)B * H * (Lp / 128) * 128 * 4);
+        }
+        auto rope = [&](const char* name, Act QKV, const float* qs, const float* ks, int tok0, const Act* qkv_base = nullptr) {
             Op o{}; o.kind = OP_FX_ROPE; o.name = name;
             o.rp = QkRopeArgs{ptr(QKV), QKV.ld, QKV.rows, L, H, D, qs, ks, nullptr, nullptr, 1e-6f};
+            if (attn8 && qkv_base) {
+                o.rp.Q8 = a8_q; o.rp.K8 = a8_k; o.rp.ld8 = C; o.rp.SQ = a8_sq; o.rp.SK = a8_sk; o.rp.s8_ld = RT; o.rp.row8 = row_of(*qkv_base, QKV);
+                snprintf(o.klabel, sizeof(o.klabel), "qk_norm_rope_mx");
+            }
             o.i0 = tok0;                                 // first token index of this slice in the pe tables
+            ops.push_back(o);
+        };
+        auto vt_quant = [&](const char* name, Act QKVb, int b) {          // QKVb: the L rows of batch b
+            Op o{}; o.kind = OP_MXVT; o.name = name;
+            o.vt = MxVtArgs{(const char*)ptr(QKVb) + (size_t)2 * C * 2, QKVb.ld, 1, H, L, a8_vt + (size_t)b * H * 128 * Lp, a8_sv + (size_t)b * H * (Lp / 128) * 128, Lp};
+            o.bytes = 3.0 * (double)L * C; snprintf(o.klabel, sizeof(o.klabel), "mx_vt_quant_kernel");
             ops.push_back(o);
         };
         auto quant = [&](const char* name, const Act& base, const Act& v, const Q8& q, int ncols = 0) {      // v: a row slice of base; its first ncols columns (0 = all)
@@ -259,7 +280,22 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
             ops.pop_back();
         };
         // returns true if the attention kernel wrote the MX shadow qo of obase itself (head dim 128, large grid)
-        auto attn = [&](const char* name, Act QKV, Act O, const Q8* qo = nullptr, const Act* obase = nullptr) {
+        auto attn = [&](const char* name, Act QKV, Act O, const Q8* qo = nullptr, const Act* obase = nullptr, int b = 0) {
+            if (attn8) {
+                Op o{}; o.kind = OP_ATTN_MX; o.name = name;
+                AttnMxArgs& a = o.am;
+                a.Q8 = a8_q + (size_t)b * L * C; a.ldq8 = C; a.SQ = a8_sq + (size_t)b * L; a.sq_ld = RT;
+                a.K8 = a8_k + (size_t)b * L * C; a.ldk8 = C; a.SK = a8_sk + (size_t)b * L; a.sk_ld = RT;
+                a.V8T = a8_vt + (size_t)b * H * 128 * Lp; a.SV = a8_sv + (size_t)b * H * (Lp / 128) * 128; a.Lp = Lp;
+                a.B = 1; a.H = H; a.Nq = L; a.Mk = L; a.scale = 1.0f / std::sqrt((float)D);
+                const bool fuse_out = qo && (fuse_mask & 2);
+                if (fuse_out) { const int ro = row_of(*obase, O); a.O8 = qo->y + (size_t)ro * qo->K; a.ldo8 = qo->K; a.SO = qo->s + ro; a.so_ld = RT; }
+                else { a.O = ptr(O); a.ldo = O.ld; }
+                o.flops = 4.0 * H * (double)L * L * D; o.bytes = (double)H * D * (2.0 * L + 2.0 * L);
+                snprintf(o.klabel, sizeof(o.klabel), "attn_mx_kernel");
+                ops.push_back(o); flops += o.flops;
+                return fuse_out;
+            }
             const char* base = (const char*)ptr(QKV);
             op_attn(name, base, QKV.ld, base + (size_t)C * 2, QKV.ld, base + (size_t)2 * C * 2, QKV.ld, O, 1, H, QKV.rows, QKV.rows, D);
             AttnArgs& a = ops.back().at;
@@ -290,8 +326,9 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 }
                 for (S& s : st) lin("fx.d.qkv", N1, s.n, qN1, s.w->qkv, s.qkv, Act{}, nullptr, s.rows, 0);
                 pair_last_two("fx.d.qkv x2");
-                for (S& s : st) rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0);
-                const bool aq = attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L), &qAO, &AO);          // joint [txt ; img] sequence
+                for (S& s : st) rope("fx.d.qknorm_rope", s.qkv, s.w->qs, s.w->ks, s.tok0, &QKV);
+                if (attn8) vt_quant("fx.d.v.mx", rows(QKV, b * L, L), b);
+                const bool aq = attn("fx.d.attn", rows(QKV, b * L, L), rows(AO, b * L, L), &qAO, &AO, b);          // joint [txt ; img] sequence
                 if (fx_fp8 && !aq) quant("fx.d.q.attn", AO, rows(AO, b * L, L), qAO);
                 for (S& s : st) {
                     const float* m = fx_mod + (size_t)b * fx_mod_total + s.w->mod_off;
@@ -326,8 +363,9 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 lin("fx.s.lin1.qkv", N1, nb, qN1, blk.lin1_qkv, qb, Act{}, nullptr, L, 0);
                 lin("fx.s.lin1.mlp", N1, nb, qN1, blk.lin1_mlp, view(cb, C, MH), Act{}, nullptr, L, 2, &qCAT, &CAT);
                 pair_last_two("fx.s.lin1 x2");                    // linear1's two halves (different epilogues) share the rounds of one launch
-                rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0);
-                const bool aq = attn("fx.s.attn", qb, view(cb, 0, C), &qCAT, &CAT);
+                rope("fx.s.qknorm_rope", qb, blk.qs, blk.ks, 0, &QKV);
+                if (attn8) vt_quant("fx.s.v.mx", qb, b);
+                const bool aq = attn("fx.s.attn", qb, view(cb, 0, C), &qCAT, &CAT, b);
                 if (fx_fp8 && !(aq && fuse_gemm_q)) quant("fx.s.q.cat", CAT, cb, qCAT, fuse_gemm_q ? C : 0);
                 lin("fx.s.lin2", CAT, cb, qCAT, blk.lin2, xb, xb, m + 2 * C, L, 0);                 // x += gate * linear2(cat)
             }

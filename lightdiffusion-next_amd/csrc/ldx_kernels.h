@@ -299,8 +299,28 @@ void launch_tile_finish(float* out, const float* div, size_t n, int clamp01, hip
 struct QkRopeArgs {
     void* QKV; int ld; int rows; int L; int H, D; const float* qscale; const float* kscale;
     const float* cosT; const float* sinT; float eps;
+    // launch_qk_norm_rope_mx only (D = 128): the normalised + rotated q / k leave as MX fp8 in ldx_op_mx_quant's format instead of being written back in 16 bit:
+    // Q8 / K8 [row8 + row][ld8] bytes (head h at columns h * 128), SQ / SK dwords [H][s8_ld] (byte j of dword [h][row8 + row] = the scale of d block j)
+    void* Q8; void* K8; int ld8; uint32_t* SQ; uint32_t* SK; int s8_ld; long row8;
 };
 void launch_qk_norm_rope(const QkRopeArgs& a, DType dt, hipStream_t s);
+void launch_qk_norm_rope_mx(const QkRopeArgs& a, DType dt, hipStream_t s);
+// MX fp8 attention for D = 128 (attn_mx.hip).  Q8 / K8 + SQ / SK: the format above, rows b * Nq + q / b * Mk + key.  V8T [B][H][128][Lp] + SV [B][H][Lp / 128][128]:
+// launch_mx_vt_quant's output (V transposed, keys in the MFMA's order inside every 64-key step, one scale per (d, 32 consecutive keys)); Lp = Mk rounded up to 128.
+// Output: 16-bit O [rows][ldo] (head h at columns h * 128), or MX fp8 O8 / SO exactly as AttnArgs::O8 / SO.
+struct AttnMxArgs {
+    const void* Q8; int ldq8; const uint32_t* SQ; int sq_ld;
+    const void* K8; int ldk8; const uint32_t* SK; int sk_ld;
+    const void* V8T; const uint32_t* SV; int Lp;
+    void* O; int ldo;
+    void* O8; int ldo8; uint32_t* SO; int so_ld;
+    int B, H, Nq, Mk; float scale;
+};
+bool attn_mx_ok(const AttnMxArgs& a);
+void launch_attn_mx(const AttnMxArgs& a, DType dt, hipStream_t s);
+// V (16 bit, rows b * L + token, head h at columns h * 128 of a row of ldv elements) -> V8T / SV (see AttnMxArgs)
+struct MxVtArgs { const void* V; int ldv; int B, H, L; void* V8T; uint32_t* SV; int Lp; };
+void launch_mx_vt_quant(const MxVtArgs& a, DType dt, hipStream_t s);
 // timestep_embedding_flux (sample/sampling_util.py:78-104): out[b][:] = [cos(1000 t f_j) | sin(1000 t f_j)], dim 256
 void launch_flux_temb(const float* t, float* out, int B, int dim, float factor, hipStream_t s);
 void launch_silu_f32(const float* in, float* out, size_t n, hipStream_t s);

@@ -545,7 +545,8 @@ class FluxEngine:
     """Flux3.forward behind BaseModel.apply_model with CONST prediction."""
 
     def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16", fp8: bool = False):
-        """fp8=True: the block linears run on MX fp8 operands (ldx_flux_set_fp8; approximate, opt-in)."""
+        """fp8=True: the block linears AND (head dim 128) QK^T / PV of the joint attention run on MX fp8 operands (ldx_flux_set_fp8 mode 1; approximate,
+        opt-in, own parity class); fp8="linears": the linears only, attention in 16 bit (mode 2, what fp8 meant through round 4)."""
         self._lib = lib.load()
         self._h = C.c_void_p()
         self.cfg, self.device = cfg, torch.device("cuda", device)
@@ -556,7 +557,7 @@ class FluxEngine:
         c.depth, c.depth_single, c.guidance_embed = cfg.depth, cfg.depth_single_blocks, int(cfg.guidance_embed)
         lib.check(self._lib.ldx_flux_create(C.byref(c), device, C.byref(self._h)), "ldx_flux_create")
         if fp8:
-            lib.check(self._lib.ldx_flux_set_fp8(self._h, 1), "ldx_flux_set_fp8")
+            lib.check(self._lib.ldx_flux_set_fp8(self._h, 2 if fp8 == "linears" else 1), "ldx_flux_set_fp8")
         _load_state_dict(self._lib, self._h, state_dict, strip=("model.diffusion_model.",))
         lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
         self._pe = {}

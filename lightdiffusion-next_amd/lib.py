@@ -108,6 +108,9 @@ _SIGS = {
     "ldx_op_conv3x3_skip": (_i, [_vp, _i, _vp, _i, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ldx_op_layernorm_mx": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_attention_mx": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "ldx_op_qk_norm_rope_mx": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _f, _vp, _vp, _i, _vp, _vp, _i, _i, _vp]),
+    "ldx_op_mx_vt_quant": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "ldx_op_attention_fp8": (_i, [_vp, _i, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
     "ldx_op_mx_quant": (_i, [_vp, _i, _i, _i, _vp, _i, _vp, _i, _i, _vp]),
     "ldx_op_gemm2": (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
     "ldx_op_gemm2_mx": (_i, [_vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _vp, _i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),

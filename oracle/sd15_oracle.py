@@ -882,10 +882,10 @@ def _rms(x, scale):
     return F.rms_norm(x, scale.shape, weight=scale, eps=1e-6)                                  # rms_norm (Flux.py:502-524)
 
 
-def _flux_attn(q, k, v, pe):
-    """attention() (Flux.py:18-33): rope then SDPA over [B,H,L,D], back to [B,L,H*D]."""
+def _flux_attn(q, k, v, pe, mx=False):
+    """attention() (Flux.py:18-33): rope then SDPA over [B,H,L,D], back to [B,L,H*D].  mx: the build's MX fp8 attention rule (mx_attention) instead of SDPA."""
     q, k = flux_apply_rope(q, k, pe)
-    o = F.scaled_dot_product_attention(q, k, v)
+    o = mx_attention(q, k, v) if mx else F.scaled_dot_product_attention(q, k, v)
     return o.transpose(1, 2).reshape(o.shape[0], o.shape[2], -1)
 
 
@@ -934,14 +934,49 @@ def mx_fake_quant(t):
     return (q * scale[..., None]).reshape(shp)
 
 
+MX_ATTN_PSH = 6          # P is rounded to e4m3 at the fixed scale 2^-6 (csrc/attn_mx.hip AM_PSH)
+
+
+def mx_attn_key_of_k(k):
+    """Key held by byte k (0..63) of a 64-key step of V8T: the contraction order of v_mfma_scale_f32_32x32x64_f8f6f4 as the P^T operand comes out of
+    the S^T accumulators (csrc/attn_mx.hip header; measured by profiles/ubench/mx_layout32.hip)."""
+    return 32 * (k >> 5) + 8 * ((k & 15) >> 2) + 4 * ((k >> 4) & 1) + (k & 3)
+
+
+def mx_fake_quant_keys(v):
+    """V of attention, [..., L, D]: MX fp8 along the KEY axis — one scale per (d, 32 consecutive keys), L padded with zeros to a multiple of 32 — dequantised."""
+    L = v.shape[-2]
+    Lp = (L + 31) // 32 * 32
+    vt = torch.zeros(v.shape[:-2] + (v.shape[-1], Lp), dtype=torch.float32)
+    vt[..., :L] = v.float().transpose(-1, -2)
+    return mx_fake_quant(vt)[..., :L].transpose(-1, -2)
+
+
+def mx_attention(q, k, v, scale=None):
+    """The build's MX fp8 attention rule (include/ldx.h ldx_op_attention_fp8; no reference counterpart — Flux.py:18-33 is SDPA in 16 bit): q, k [B,H,L,D]
+    quantised along d, v along the keys, T = q k^T * scale * log2(e), P = 2^(T - ceil(row max of T)) rounded to e4m3 at the fixed scale 2^-6,
+    O = P8 v / sum of P8 (the rounded values: the kernel gets the row sums from an all-ones row of V^T).  The reference exponent is an INTEGER: the kernel's lazily updated one may sit up to two below it, i.e. its P is
+    this P times 1, 2 or 4 — the same e4m3 mantissas (a floating format), only the subnormal boundary (2^-15 relative and below) moves."""
+    d = q.shape[-1]
+    scale = (1.0 / math.sqrt(d)) if scale is None else scale
+    qf, kf, vf = mx_fake_quant(q.float()), mx_fake_quant(k.float()), mx_fake_quant_keys(v)
+    t = (qf.double() @ kf.double().transpose(-1, -2)) * (np.float32(scale) * np.float32(1.44269504088896340736))
+    p = torch.exp2(t - torch.ceil(t.amax(-1, keepdim=True)))
+    p8 = (p * 2.0 ** MX_ATTN_PSH).float().to(torch.float8_e4m3fn).double() / 2.0 ** MX_ATTN_PSH
+    return ((p8 @ vf.double()) / p8.sum(-1, keepdim=True)).float()          # the denominator sums the ROUNDED P (a ones row of V^T on the matrix pipe)
+
+
 _MX_LINEARS = ("_attn.qkv", "_attn.proj", "_mlp.0", "_mlp.2", ".linear1", ".linear2")
 
 
-def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False):
+def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False, mx_attn=None):
     """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output.
     fb: optional FluxFBCache (approximate mode).  mx: the build's MX fp8 mode — input and weight of every double / single
-    block linear pass through mx_fake_quant (fp32 accumulation, everything else unchanged)."""
+    block linear pass through mx_fake_quant (fp32 accumulation, everything else unchanged); mx_attn (default: = mx when the head dim is 128, the build's
+    ldx_flux_set_fp8 mode 1): the joint attention follows mx_attention as well; mx_attn=False = mode 2 (linears only)."""
     w = W(sd)
+    if mx_attn is None:
+        mx_attn = bool(mx) and cfg.hidden_size // cfg.num_heads == 128
 
     def lin(name, t):
         wt = w(name + ".weight")
@@ -983,7 +1018,7 @@ def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False):
         iq, ik = _rms(iq, w(p + "img_attn.norm.query_norm.scale")), _rms(ik, w(p + "img_attn.norm.key_norm.scale"))
         tq, tk, tv = heads(lin(p + "txt_attn.qkv", (1 + tm[1]) * ln(txt) + tm[0]))
         tq, tk = _rms(tq, w(p + "txt_attn.norm.query_norm.scale")), _rms(tk, w(p + "txt_attn.norm.key_norm.scale"))
-        attn = _flux_attn(torch.cat((tq, iq), 2), torch.cat((tk, ik), 2), torch.cat((tv, iv), 2), pe)
+        attn = _flux_attn(torch.cat((tq, iq), 2), torch.cat((tk, ik), 2), torch.cat((tv, iv), 2), pe, mx_attn)
         ta, ia = attn[:, :lt], attn[:, lt:]
         img = img + im[2] * lin(p + "img_attn.proj", ia)
         img = img + im[5] * lin(p + "img_mlp.2", F.gelu(lin(p + "img_mlp.0", (1 + im[4]) * ln(img) + im[3]), approximate="tanh"))
@@ -1006,7 +1041,7 @@ def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False):
         qkv, mlp = torch.split(lin(p + "linear1", (1 + scale) * ln(xj) + shift), [3 * C, cfg.mlp_hidden], dim=-1)
         q, k, v = heads(qkv)
         q, k = _rms(q, w(p + "norm.query_norm.scale")), _rms(k, w(p + "norm.key_norm.scale"))
-        attn = _flux_attn(q, k, v, pe)
+        attn = _flux_attn(q, k, v, pe, mx_attn)
         xj = xj + gate * lin(p + "linear2", torch.cat((attn, F.gelu(mlp, approximate="tanh")), 2))
     img = xj[:, lt:]
     if fb is not None:
