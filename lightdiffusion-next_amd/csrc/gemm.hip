@@ -774,6 +774,7 @@ void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s)
 
 void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
+    if (a.mode == 1 && conv_patch_ok(a)) { launch_conv_patch(a, dt, s); return; }      // conv_patch.hip: narrow 3x3 convs with the input patch resident in LDS
     if (dt == DT_BF16) launch_gemm_t<__bf16>(a, s); else launch_gemm_t<_Float16>(a, s);
 }
 

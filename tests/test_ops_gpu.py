@@ -126,6 +126,44 @@ def test_conv3x3(L, ldx, dt, case):
     _check(Y, ref, dt, what=f"conv {case}")
 
 
+PATCH_CASES = [
+    # B, Hin, Win, Cin, Cout, Hout, Wout, resize, ldx_extra, residual   (conv_patch.hip: Cout 32 / 64, 16 x 16 tiles, >= 256 of them)
+    (1, 256, 256, 64, 32, 256, 256, 0, 128, 0),      # ESRGAN RDB conv1: reads 64 of 192 columns
+    (1, 256, 256, 192, 64, 256, 256, 0, 0, 1),       # RDB conv5: 6 channel chunks, residual
+    (2, 128, 256, 128, 32, 128, 256, 0, 32, 0),      # 4 chunks, two images, non-square
+    (1, 128, 128, 64, 64, 256, 256, 1, 0, 0),        # nearest x2 + conv (upconv_block)
+    (1, 112, 200, 64, 64, 272, 304, 1, 0, 1),        # non-integer resize ratios
+]
+
+
+@pytest.mark.parametrize("dt", ["bf16", "f16"])
+@pytest.mark.parametrize("case", PATCH_CASES)
+def test_conv3x3_patch_resident(L, ldx, dt, case):
+    """The narrow-output 3x3 convs that launch_gemm routes to conv_patch.hip (USDU_util.py:36-98 conv_block / :101-128 upconv_block shapes):
+    borders (zero padding from the buffer bounds check), halo sharing between tiles, the resize gather, strided input views."""
+    td, code = DT[dt]
+    B, Hin, Win, Cin, Cout, Hout, Wout, resize, extra, res = case
+    g = torch.Generator(device="cuda").manual_seed(sum(case))
+    ld = Cin + extra
+    X = torch.randn(B, Hin, Win, ld, device="cuda", generator=g).to(td)
+    Wt = (torch.randn(Cout, Cin, 3, 3, device="cuda", generator=g) / math.sqrt(9 * Cin)).to(td)
+    Wp = Wt.permute(0, 2, 3, 1).reshape(Cout, 9 * Cin).contiguous()
+    bias = torch.randn(Cout, device="cuda", generator=g)
+    R = torch.randn(B * Hout * Wout, Cout + 8, device="cuda", generator=g).to(td) if res else None
+    Y = torch.zeros(B * Hout * Wout, Cout + 16, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_conv3x3(_p(X), ld, _p(Wp), B, Hin, Win, Cin, Cout, 1, Hout, Wout, resize, _p(bias),
+                                   None, 0, _p(R), Cout + 8, _p(Y), Cout + 16, code, _st()), "conv")
+    torch.cuda.synchronize()
+    xin = X[..., :Cin].float().permute(0, 3, 1, 2)
+    if resize:
+        xin = F.interpolate(xin, size=(Hout, Wout), mode="nearest")
+    ref = F.conv2d(xin, Wt.float(), bias, padding=1).permute(0, 2, 3, 1).reshape(B * Hout * Wout, Cout)
+    if res:
+        ref = ref + R[:, :Cout].float()
+    _check(Y[:, :Cout], ref, dt, what=f"patch conv {case}")
+    assert float(Y[:, Cout:].abs().max()) == 0.0          # nothing written beyond the Cout columns of the view
+
+
 @pytest.mark.parametrize("dt", ["bf16", "f16"])
 @pytest.mark.parametrize("B,H,W,Cin,Cin2,Cout", [(2, 16, 16, 1280, 2560, 1280),     # split-K 11: several splits start inside the second segment
                                                  (2, 32, 32, 640, 1280, 640), (1, 24, 20, 128, 64, 192), (2, 64, 64, 320, 640, 320)])
