@@ -675,6 +675,15 @@ void gemm_gn_tile_check(const GemmArgs& a, int BM, int BN, int S) {
 int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
     static const bool off = getenv("LDX_GN_FUSE") && atoi(getenv("LDX_GN_FUSE")) == 0;
     if (off || a.f8 || a.C8 || a.geglu || a.ln_c1 || !a.C || G <= 0 || a.N % G || a.N % 4 || HW <= 0 || a.M % HW) return 0;
+    if (a.mode == 1) {                        // conv_patch.hip takes it: one chunk per 32 x 16-pixel tile (N = 128 only), or no fusion
+        GemmArgs t = a; t.gn_partial = nullptr;
+        if (conv_patch_ok(t)) {
+            const int nc = conv_patch_gn_chunks(a, HW, G);
+            if (!nc || nc > max_chunks) return 0;
+            a.gn_cpg = a.N / G; a.gn_G = G; a.gn_hw = HW; a.gn_nchunk = nc;
+            return nc;
+        }
+    }
     const bool fix = gemm_sk_fixup(a);        // in-kernel split-K reduction: the last workgroup of a tile runs the ordinary epilogue, statistics included
     if (a.splitk > 1 && a.ws && !fix) {        // split-K with a reduce launch: that launch produces the statistics (splitk_reduce_gn_kernel)
         static const bool sk_off = getenv("LDX_GN_FUSE_SPLITK") && atoi(getenv("LDX_GN_FUSE_SPLITK")) == 0;

@@ -15,8 +15,9 @@ constexpr int BK = 64;
 // gemm_ring.hip: 64 x 160 LDS-DMA ring tiles for mid-size plain GEMMs; gemm_tile (gemm.hip) asks gemm_ring_ok
 bool gemm_ring_ok(int M, int N, int K, bool plain, int splitk);
 void launch_gemm_ring(const GemmArgs& a, DType dt, hipStream_t s);
-// conv_patch.hip: patch-resident 3x3 conv for N = 32 / 64 (ESRGAN); launch_gemm asks conv_patch_ok
+// conv_patch.hip: patch-resident 3x3 conv for N = 32 / 64 / 128 (ESRGAN, VAE last level); launch_gemm asks conv_patch_ok
 bool conv_patch_ok(const GemmArgs& a);
+int conv_patch_gn_chunks(const GemmArgs& a, int HW, int G);
 void launch_conv_patch(const GemmArgs& a, DType dt, hipStream_t s);
 // BN is a template parameter: 128 (generic) or 160 — every SD1.5 channel count is a multiple of 320, and
 // 160-wide tiles remove the half-empty last column tile (and the half-empty last round of workgroups)

@@ -20,6 +20,8 @@ print(f"RRDBNet x4 512^2 -> 2048^2: {dt*1e3:.1f} ms  {info['flops']/dt/1e12:.0f}
 eng.profile(True); eng.forward(x); torch.cuda.synchronize(); eng.profile(False, reset=False)
 for k, v in sorted(eng.profile_report().items(), key=lambda kv: -kv[1]["ms"])[:4]:
     print(f"  {k:30s} n={v['count']:4d} {v['ms']:.2f} ms" + (f"  {v['flops']/v['ms']/1e9:.0f} TF" if v['flops'] else ""))
+if len(sys.argv) > 1 and sys.argv[1] == "quick":
+    sys.exit(0)
 img = torch.rand(1, 1024, 1024, 3)
 for _ in range(2):
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -127,12 +127,15 @@ def test_conv3x3(L, ldx, dt, case):
 
 
 PATCH_CASES = [
-    # B, Hin, Win, Cin, Cout, Hout, Wout, resize, ldx_extra, residual   (conv_patch.hip: Cout 32 / 64, 16 x 16 tiles, >= 256 of them)
-    (1, 256, 256, 64, 32, 256, 256, 0, 128, 0),      # ESRGAN RDB conv1: reads 64 of 192 columns
-    (1, 256, 256, 192, 64, 256, 256, 0, 0, 1),       # RDB conv5: 6 channel chunks, residual
-    (2, 128, 256, 128, 32, 128, 256, 0, 32, 0),      # 4 chunks, two images, non-square
-    (1, 128, 128, 64, 64, 256, 256, 1, 0, 0),        # nearest x2 + conv (upconv_block)
-    (1, 112, 200, 64, 64, 272, 304, 1, 0, 1),        # non-integer resize ratios
+    # B, Hin, Win, Cin, Cout, Hout, Wout, resize, ldx_extra, residual   (conv_patch.hip: Cout 32 / 64 / 128, 32 x 16-pixel tiles, >= 256 of them)
+    (1, 256, 512, 64, 32, 256, 512, 0, 128, 0),      # ESRGAN RDB conv1: reads 64 of 192 columns; one tile per workgroup
+    (1, 256, 512, 192, 64, 256, 512, 0, 0, 1),       # RDB conv5: 6 channel chunks, residual
+    (2, 128, 512, 128, 32, 128, 512, 0, 32, 0),      # 4 chunks, two images
+    (1, 128, 256, 64, 64, 256, 512, 1, 0, 0),        # nearest x2 + conv (upconv_block)
+    (1, 150, 111, 64, 64, 400, 352, 1, 0, 1),        # non-integer resize ratios, 275 tiles (uneven tiles per workgroup)
+    (1, 256, 512, 128, 128, 256, 512, 0, 0, 1),      # VAE last level 128 -> 128
+    (1, 272, 544, 64, 128, 272, 544, 0, 64, 0),      # 289 tiles: some workgroups walk two
+    (1, 512, 1024, 64, 32, 512, 1024, 0, 0, 0),      # 1024 tiles: four per workgroup, the load stream crosses three tile boundaries
 ]
 
 
