@@ -316,7 +316,7 @@ def flux_lines(ldx, steps=28):
                             latent_image=torch.zeros(1, 16, 128, 128), guidance=3.0)
             torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         assert torch.isfinite(lat).all() and torch.isfinite(o).all()
-        out[name] = {"workload": f"Flux.1-dev DiT 19+38 blocks (11.9 B synthetic params), 1024^2 = 4096 image + 256 text tokens, {'MX fp8 (e4m3 + E8M0 per 32)' if fp8 else 'bf16'} linears",
+        out[name] = {"workload": f"Flux.1-dev DiT 19+38 blocks (11.9 B synthetic params), 1024^2 = 4096 image + 256 text tokens, {'MX fp8 (e4m3 + E8M0 per 32) linears AND attention (QK^T / PV on the block-scaled MFMA, csrc/attn_mx.hip)' if fp8 else 'bf16 linears and attention'}",
                      "ms_per_forward_bs1": round(fwd_ms, 2), "forward_tflop": round(info1["flops"] / 1e12, 2),
                      "sampler": f"FluxKSampler euler_cfgpp/beta, {steps} steps, cfg 1 with a zeroed negative (batch-2 evaluations, second run of 2)",
                      "sampler_s": round(ts[-1], 3), "it_per_s": round(steps / ts[-1], 3), "launches": info1["launches"], "kernels": kern,
