@@ -190,6 +190,7 @@ struct RowGemmArgs {
     // gn_out != null (engine only, pro != 2, N == K): the consumer of Y is a GroupNorm over [M / HW][HW][N] — every workgroup also writes the sum / sum of
     // squares of the 16-bit values it stores, per group, to gn_out[b][chunk = its row block within the image][32][2] (gn_nchunk = HW / rows per block)
     float* gn_out; int gn_nchunk;
+    int abl;                       // timing ablations (LDX_RG_ABL, set by the launcher; wrong results): 1 no residual loads, 2 no MFMA loop, 4 no row loads, 8 no stores
 };
 bool rowgemm_ok(const RowGemmArgs& a);
 void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s);

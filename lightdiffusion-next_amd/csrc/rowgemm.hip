@@ -89,7 +89,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
         const long m = m0 + row;
         uint4 raw[10];
 #pragma unroll
-        for (int j = 0; j < 10; ++j) raw[j] = (m < p.M) ? *(const uint4*)(Xp + m * p.ldx + (part + LPR * j) * 8) : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < 10; ++j) raw[j] = (m < p.M && !(p.abl & 4)) ? *(const uint4*)(Xp + m * p.ldx + (part + LPR * j) * 8) : make_uint4(0, 0, 0, 0);
         if (PRO == 0) {
 #pragma unroll
             for (int j = 0; j < 10; ++j) *(uint4*)(sA + row * RG_AROW + (part + LPR * j) * 16) = raw[j];
@@ -153,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
         };
 #pragma unroll
         for (int ks = 0; ks < PD; ++ks) wload(ks, ks);
+        if (!(p.abl & 2))
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
             if (ks + PD < NKS) wload(ks + PD, (ks + PD) % (PD + 1));
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
             for (int qt = 0; qt < QT; ++qt) {
                 const long m = m0 + 16 * qt + l15;
                 const int nl = 16 * t + 4 * g4;
-                rr[t][qt] = (p.R && m < p.M && nl < 40) ? *(const uint2*)((const T*)p.R + m * p.ldr + wrow0 + nl) : make_uint2(0u, 0u);
+                rr[t][qt] = (p.R && m < p.M && nl < 40 && !(p.abl & 1)) ? *(const uint2*)((const T*)p.R + m * p.ldr + wrow0 + nl) : make_uint2(0u, 0u);
             }
 #pragma unroll
         for (int t = 0; t < 3; ++t) {
@@ -221,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
                 p.gn_out[(((long)bimg * p.gn_nchunk + chunk) * 32 + g0 + gl) * 2 + st] = a;
             }
         }
-        rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB);
+        if (!(p.abl & 8)) rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB);
     }
 }
 
@@ -249,7 +250,9 @@ static void launch_rowgemm_t(const RowGemmArgs& a, hipStream_t s) {
         if (a.pro == 0) launch_rowgemm_inst<T, 0, 640>(a, s); else if (a.pro == 1) launch_rowgemm_inst<T, 1, 640>(a, s); else launch_rowgemm_inst<T, 2, 640>(a, s);
     }
 }
-void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s) {
+void launch_rowgemm(const RowGemmArgs& a0, DType dt, hipStream_t s) {
+    static const int abl = getenv("LDX_RG_ABL") ? atoi(getenv("LDX_RG_ABL")) : 0;
+    RowGemmArgs a = a0; a.abl = abl;
     if (dt == DT_BF16) launch_rowgemm_t<__bf16>(a, s); else launch_rowgemm_t<_Float16>(a, s);
 }
 

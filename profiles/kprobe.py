@@ -150,10 +150,11 @@ if __name__ == "__main__":
         h = rn(M, Cc).bfloat16(); gamma, beta = 1 + 0.1 * rn(Cc), 0.1 * rn(Cc)
         Wq = (rn(Cc, Cc) / math.sqrt(Cc)).bfloat16(); Wo = (rn(Cc, Cc) / math.sqrt(Cc)).bfloat16(); bo = 0.1 * rn(Cc)
         Wqkv = (rn(3 * Cc, Cc) / math.sqrt(Cc)).bfloat16(); qkv = torch.empty(M, 3 * Cc, device="cuda", dtype=torch.bfloat16)
-        kv = rn(2 * Mk, 2 * Cc).bfloat16()
+        kv = rn(2 * Mk, 2 * Cc).bfloat16(); h2 = rn(M, Cc).bfloat16()
         W1 = (rn(2 * inner, Cc) / math.sqrt(Cc)).bfloat16(); b1 = 0.1 * rn(2 * inner); W2 = (rn(Cc, inner) / math.sqrt(inner)).bfloat16(); b2 = 0.1 * rn(Cc)
         for name, fl, fn in (
             ("rowgemm LN + q|k|v (N = 960)", 2.0 * M * 960 * Cc, lambda: L.ldx_op_rowgemm(p(h), Cc, p(qkv), 3 * Cc, M, 3 * Cc, Cc, p(Wqkv), None, None, 0, 1, p(gamma), p(beta), 1e-5, None, 0, 0, 0, st())),
+            ("rowgemm to_out + residual (N = 320)", 2.0 * M * Cc * Cc, lambda: L.ldx_op_rowgemm(p(h), Cc, p(h2), Cc, M, Cc, Cc, p(Wq), p(bo), p(h2), Cc, 0, None, None, 1e-5, None, 0, 0, 0, st())),
             ("xattn_block (77 keys)", 4.0 * M * Cc * Cc + 4.0 * M * Mk * Cc, lambda: L.ldx_op_xattn_block(p(h), Cc, M, M // 2, Cc, 8, p(gamma), p(beta), 1e-5, p(Wq), p(Wo), p(bo), p(kv), 2 * Cc, p(kv[:, Cc:]), 2 * Cc, Mk, 1 / math.sqrt(40), 0, st())),
             ("ff_block (inner 1280)", 2.0 * M * Cc * 3 * inner, lambda: L.ldx_op_ff_block(p(h), Cc, M, Cc, inner, p(gamma), p(beta), 1e-5, p(W1), p(b1), p(W2), p(b2), 0, st()))):
             ms = timeit_graph(fn, 20)
