@@ -532,6 +532,21 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
             for (int j = 0; j < NJ; ++j) {
                 const int n = j * 16 + 4 * g4;
                 float v[4] = {acc[r][j][0], acc[r][j][1], acc[r][j][2], acc[r][j][3]};
+                if constexpr (NJ == 1) {     // N <= 16 (conv_last / conv_out with 3 or 4 channels: weight rows >= N read as zeros): element-wise tail, no residuals
+                    if (n < p.N) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            if (n + q < p.N) {
+                                float x = v[q] + (p.bias ? p.bias[n + q] : 0.f);
+                                if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+                                if (p.oscale != 0.f) x *= p.oscale;
+                                if (Cp && !(abl & 8)) Cp[m * p.ldc + n + q] = from_f32<T>(x);
+                                if (p.Cf) p.Cf[m * p.ldcf + n + q] = x;
+                            }
+                        }
+                    }
+                    continue;
+                }
                 if (p.bias) { const float4 bv = *(const float4*)(p.bias + n); v[0] += bv.x; v[1] += bv.y; v[2] += bv.z; v[3] += bv.w; }
                 if (p.act == 3) {
 #pragma unroll
@@ -549,14 +564,17 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
 }
 
 // Which (PR, RW) the launcher instantiates per N, and the LDS they need
+static bool cp_ws_enabled() { static const bool ws = !(getenv("LDX_CONV_PATCH_WS") && atoi(getenv("LDX_CONV_PATCH_WS")) == 0); return ws; }      // 0: every wave loads and multiplies (the kernel N = 128 uses)
 static bool cp_disabled() { static const bool off = getenv("LDX_CONV_PATCH") && atoi(getenv("LDX_CONV_PATCH")) == 0; return off; }
 
 bool conv_patch_ok(const GemmArgs& a) {
     if (cp_disabled() || a.mode != 1 || a.stride != 1 || a.A2 || a.pad0 || a.f8 || a.C8 || a.ln_c1 || a.geglu || a.rowvec || a.gate || a.splitk > 1) return false;
-    if (a.N != 32 && a.N != 64 && a.N != 128) return false;
+    const bool narrow = a.N <= 16;      // conv_last / conv_out: 3 or 4 output channels, element-wise epilogue (no residuals), loader-wave kernel with one column tile
+    if (!narrow && a.N != 32 && a.N != 64 && a.N != 128) return false;
+    if (narrow && (a.R || a.R2 || a.gn_partial || !cp_ws_enabled())) return false;
     if (a.act != 0 && a.act != 3) return false;
     if (a.Cin % 64 || a.Cin < 64 || a.K != 9 * a.Cin || a.Hout % CP_TH || a.Wout % CP_TW || a.Hv != a.Hout || a.Wv != a.Wout) return false;      // Cin % 64: 3 Cin / 32 steps in groups of 6
-    if (a.lda % 8 || (a.C && a.ldc % 4) || (a.R && a.ldr % 4) || (a.R2 && a.ldr2 % 4) || (a.Cf && a.ldcf % 4)) return false;
+    if (a.lda % 8 || (!narrow && ((a.C && a.ldc % 4) || (a.R && a.ldr % 4) || (a.R2 && a.ldr2 % 4) || (a.Cf && a.ldcf % 4)))) return false;
     const long nimg = a.M / ((long)a.Hout * a.Wout);
     if (nimg * a.Hin * a.Win * a.lda * 2 >= 0x7fffffffL) return false;      // 32-bit buffer offsets
     const long ntiles = nimg * (a.Hout / CP_TH) * (a.Wout / CP_TW);
@@ -597,8 +615,9 @@ static void launch_conv_patch_ws(const GemmArgs& a, hipStream_t s) {
 
 template <typename T>
 static void launch_conv_patch_n(const GemmArgs& a, hipStream_t s) {
-    static const bool ws = !(getenv("LDX_CONV_PATCH_WS") && atoi(getenv("LDX_CONV_PATCH_WS")) == 0);      // 0: every wave loads and multiplies (the kernel N = 128 uses)
-    if (a.N == 32) { if (ws) launch_conv_patch_ws<T, 2, 3, 6>(a, s); else launch_conv_patch_t<T, 2, 3, 6>(a, s); }
+    const bool ws = cp_ws_enabled();
+    if (a.N <= 16) launch_conv_patch_ws<T, 1, 3, 6>(a, s);
+    else if (a.N == 32) { if (ws) launch_conv_patch_ws<T, 2, 3, 6>(a, s); else launch_conv_patch_t<T, 2, 3, 6>(a, s); }
     else if (a.N == 64) { if (ws) launch_conv_patch_ws<T, 4, 2, 6>(a, s); else launch_conv_patch_t<T, 4, 2, 6>(a, s); }
     else launch_conv_patch_t<T, 8, 2, 3>(a, s);
 }

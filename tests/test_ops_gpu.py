@@ -136,6 +136,8 @@ PATCH_CASES = [
     (1, 256, 512, 128, 128, 256, 512, 0, 0, 1),      # VAE last level 128 -> 128
     (1, 272, 544, 64, 128, 272, 544, 0, 64, 0),      # 289 tiles: some workgroups walk two
     (1, 512, 1024, 64, 32, 512, 1024, 0, 0, 0),      # 1024 tiles: four per workgroup, the load stream crosses three tile boundaries
+    (1, 256, 512, 64, 3, 256, 512, 0, 0, 0),         # conv_last / conv_out: 3 channels (weight rows 3 .. 15 read as zeros), element-wise tail
+    (1, 256, 512, 128, 4, 256, 512, 0, 64, 0),       # UNet out conv shape: 4 channels
 ]
 
 
