@@ -182,3 +182,12 @@ if __name__ == "__main__":
             fn(); torch.cuda.synchronize()
             err = float((Cc.float() - ref).norm() / ref.norm())
             print(f"gemm+residual {M}x{N}x{K}: rel-L2 {err:.1e}  {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s  {(M * K + 2 * M * N) * 2 / ms / 1e6:.0f} GB/s")
+    if what == "small":    # the latency-bound projections of the 512^2 / 1024^2 steps (64 x 64 tiles): run with LDX_RING64=0 / 1
+        for s in ((512, 1280, 1280), (2048, 640, 640), (8192, 320, 320), (8192, 320, 1280), (2048, 1280, 1280), (512, 1280, 5120), (128, 1280, 1280), (8192, 640, 640), (8192, 640, 2560)):
+            ms = timeit_graph(lambda: None, 1) if False else None
+            M, N, K = s
+            A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16(); Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+            bias = torch.randn(N, device="cuda"); R = torch.randn(M, N, device="cuda").bfloat16()
+            fn = lambda: L.ldx_op_gemm(p(A), K, p(Wt), M, N, K, p(bias), None, 0, 1, 0, p(R), N, p(Cc), N, None, 0, 0, st())
+            ms = timeit_graph(fn, 50)
+            print(f"gemm {M}x{N}x{K} + bias + residual: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
