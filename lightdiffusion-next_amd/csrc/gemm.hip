@@ -355,6 +355,40 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs a, const G
     else gemm_tile_body<T, 0, BM, BN, 2, F8>(b, blockIdx.x - tiles_a);
 }
 
+// The split-K reduce launches' epilogue operands for one row and 4 consecutive columns (n % 4 == 0, n + 3 < N)
+struct SkOperands { float4 bias, rv, gate; float r[4], r2[4]; };
+template <typename T>
+static __device__ __forceinline__ void sk_load_operands(const GemmArgs& p, const long m, const int n, const float* rv, SkOperands& o) {
+    const float* zf = p.ws;                  // readable, 16-byte aligned: what a missing operand loads (and the select below drops)
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    const float4 tb = *(const float4*)(p.bias ? p.bias + n : zf);
+    const float4 tr = *(const float4*)(rv ? rv + n : zf);
+    const float4 tg = *(const float4*)(p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld + n : zf);
+    const uint2 t1 = *(const uint2*)(p.R ? (const void*)((const T*)p.R + m * p.ldr + n) : (const void*)zf);
+    const uint2 t2 = *(const uint2*)(p.R2 ? (const void*)((const T*)p.R2 + m * p.ldr2 + n) : (const void*)zf);
+    o.bias = p.bias ? tb : z4; o.rv = rv ? tr : z4; o.gate = p.gate ? tg : make_float4(1.f, 1.f, 1.f, 1.f);
+    unpack4<T>(t1, o.r); unpack4<T>(t2, o.r2);
+}
+// v -> the stored values, in gemm_epilogue's operation order
+template <typename T>
+static __device__ __forceinline__ void sk_apply_operands(const GemmArgs& p, const SkOperands& o, float (&v)[4]) {
+    const float bb[4] = {o.bias.x, o.bias.y, o.bias.z, o.bias.w}, rr[4] = {o.rv.x, o.rv.y, o.rv.z, o.rv.w}, gg[4] = {o.gate.x, o.gate.y, o.gate.z, o.gate.w};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        float x = v[c];
+        if (p.bias) x += bb[c];
+        if (p.rowvec) x += rr[c];
+        if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+        else if (p.act == 2) x = gelu_tanh_f(x);
+        else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+        if (p.gate) x *= gg[c];
+        if (p.oscale != 0.f) x *= p.oscale;
+        if (p.R) x += o.r[c];
+        if (p.R2) x = fmaf(x, p.oscale2, o.r2[c]);
+        v[c] = x;
+    }
+}
+
 // sum the split-K partials (fixed order -> deterministic) and apply the epilogue; one thread per 4 columns
 template <typename T>
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
@@ -387,6 +421,14 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             }
         }
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        if (full) {
+            // Epilogue operands as UNCONDITIONAL 16 / 8-byte loads (a null operand reads the workspace instead and is discarded by a select): written as
+            // `if (p.bias) x += p.bias[n + r]` per element, hipcc emitted one global load + s_waitcnt vmcnt(0) per element and operand — two dozen memory
+            // latencies in a row, 13 - 31 us per reduce launch, 0.65 ms of the 1024^2 step (profiles/r05/bench_kernel_stats.csv).  Same operations, same order.
+            SkOperands o;
+            sk_load_operands<T>(p, m, n, rv, o);
+            sk_apply_operands<T>(p, o, v);
+        } else
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
             float x = v[r];
             if (p.bias) x += p.bias[n + r];
@@ -424,43 +466,45 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
     const int RB = p.gn_hw / p.gn_nchunk;
     const int b = blockIdx.y, chunk = blockIdx.x;
     const long row0 = (long)b * p.gn_hw + (long)chunk * RB;
-    const T* __restrict__ Rp = (const T*)p.R;
     T* __restrict__ Cp = (T*)p.C;
     const size_t stride = (size_t)p.M * p.N;
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     if (rl < R) {
-        constexpr int U = 8;                    // rows in flight per thread (the partial loads of U rows are issued together)
+        // U rows x SB splits of partial loads in flight per thread.  (Round 5: with one split at a time a chunk of R rows — one row per thread, what the
+        // 16^2 / 32^2 levels get — paid one memory latency per split: 20 us for S = 11 at M = 512, as long as the GEMM in front of it.)  The adds stay in
+        // split order: same bits as before.
+        constexpr int U = 2, SB = 4;
         for (int r = rl; r < RB; r += R * U) {
             float v[U][4];
             bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { live[u] = r + u * R < RB; v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f; }
-            for (int sidx = 0; sidx < p.splitk; ++sidx) {
-                float4 t[U];
+            for (int s0 = 0; s0 < p.splitk; s0 += SB) {
+                float4 t[U][SB];
 #pragma unroll
-                for (int u = 0; u < U; ++u) t[u] = live[u] ? *(const float4*)(p.ws + (size_t)sidx * stride + (size_t)(row0 + r + u * R) * p.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int u = 0; u < U; ++u)
 #pragma unroll
-                for (int u = 0; u < U; ++u) { v[u][0] += t[u].x; v[u][1] += t[u].y; v[u][2] += t[u].z; v[u][3] += t[u].w; }
+                    for (int sb = 0; sb < SB; ++sb)
+                        t[u][sb] = (live[u] && s0 + sb < p.splitk) ? *(const float4*)(p.ws + (size_t)(s0 + sb) * stride + (size_t)(row0 + r + u * R) * p.N + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+                for (int sb = 0; sb < SB; ++sb) {
+                    if (s0 + sb < p.splitk) {      // (adding the zeros of a missing split would turn a -0 sum into +0)
+#pragma unroll
+                        for (int u = 0; u < U; ++u) { v[u][0] += t[u][sb].x; v[u][1] += t[u][sb].y; v[u][2] += t[u][sb].z; v[u][3] += t[u][sb].w; }
+                    }
+                }
             }
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 if (!live[u]) continue;
                 const long m = row0 + r + u * R;
                 const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+                SkOperands o;                                     // vector loads, no per-element branches (see splitk_reduce_kernel)
+                sk_load_operands<T>(p, m, n, rv, o);
+                sk_apply_operands<T>(p, o, v[u]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    float x = v[u][c];
-                    if (p.bias) x += p.bias[n + c];
-                    if (rv) x += rv[n + c];
-                    if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
-                    else if (p.act == 2) x = gelu_tanh_f(x);
-                    else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
-                    if (p.gate) x *= p.gate[(long)(m / p.rows_per_batch) * p.gate_ld + n + c];
-                    if (p.oscale != 0.f) x *= p.oscale;
-                    if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + c]);
-                    if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + c]));
-                    v[u][c] = x;
-                    const float xr = to_f32(from_f32<T>(x));      // statistics of the values as stored
+                    const float xr = to_f32(from_f32<T>(v[u][c]));      // statistics of the values as stored
                     gs[c] += xr; gq[c] = fmaf(xr, xr, gq[c]);
                 }
                 *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[u][0], v[u][1], v[u][2], v[u][3]);

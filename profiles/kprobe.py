@@ -188,6 +188,7 @@ if __name__ == "__main__":
             M, N, K = s
             A = torch.randn(M, K, device="cuda").bfloat16(); Wt = (torch.randn(N, K, device="cuda") / math.sqrt(K)).bfloat16(); Cc = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
             bias = torch.randn(N, device="cuda"); R = torch.randn(M, N, device="cuda").bfloat16()
-            fn = lambda: L.ldx_op_gemm(p(A), K, p(Wt), M, N, K, p(bias), None, 0, 1, 0, p(R), N, p(Cc), N, None, 0, 0, st())
+            noepi = os.environ.get("NOEPI") == "1"      # no bias / residual: what the epilogue operands cost
+            fn = lambda: L.ldx_op_gemm(p(A), K, p(Wt), M, N, K, None if noepi else p(bias), None, 0, 1, 0, None if noepi else p(R), N, p(Cc), N, None, 0, 0, st())
             ms = timeit_graph(fn, 50)
             print(f"gemm {M}x{N}x{K} + bias + residual: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
