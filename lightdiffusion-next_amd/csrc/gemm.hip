@@ -515,7 +515,15 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
         for (int c = 0; c < 4; ++c) { red_gn[((long)rl * p.N + n + c) * 2] = gs[c]; red_gn[((long)rl * p.N + n + c) * 2 + 1] = gq[c]; }
     }
     __syncthreads();
-    if (tid < p.gn_G * 2) {
+    // 8 lanes per (group, statistic): lane k adds elements k, k + 8, .. of the R x cpg column sums, then a 3-step butterfly — a fixed tree, so still
+    // deterministic (one thread per pair walked 80 dependent LDS reads at N = 1280: ~4 us of a 14 us launch)
+    if (tid < p.gn_G * 2 * 8 && (int)blockDim.x >= p.gn_G * 2 * 8) {
+        const int pr = tid >> 3, k = tid & 7, g = pr >> 1, st = pr & 1, c0 = g * p.gn_cpg, ne = R * p.gn_cpg;
+        float a = 0.f;
+        for (int e = k; e < ne; e += 8) { const int l = e / p.gn_cpg, c = e - l * p.gn_cpg; a += red_gn[((long)l * p.N + c0 + c) * 2 + st]; }
+        a += __shfl_xor(a, 1); a += __shfl_xor(a, 2); a += __shfl_xor(a, 4);
+        if (k == 0) p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + g) * 2 + st] = a;
+    } else if ((int)blockDim.x < p.gn_G * 2 * 8 && tid < p.gn_G * 2) {
         const int g = tid >> 1, st = tid & 1, c0 = g * p.gn_cpg;
         float a = 0.f;
         for (int l = 0; l < R; ++l)
