@@ -192,3 +192,20 @@ if __name__ == "__main__":
             fn = lambda: L.ldx_op_gemm(p(A), K, p(Wt), M, N, K, None if noepi else p(bias), None, 0, 1, 0, None if noepi else p(R), N, p(Cc), N, None, 0, 0, st())
             ms = timeit_graph(fn, 50)
             print(f"gemm {M}x{N}x{K} + bias + residual: {ms * 1000:.1f} us  {2.0 * M * N * K / ms / 1e9:.1f} TFLOP/s")
+    if what == "convepi":  # what the epilogue operands (bias, per-batch row vector, residual) cost on the level-0 conv shapes
+        for (B, H, Cin, Cout) in ((2, 128, 320, 320), (2, 128, 640, 320), (2, 64, 640, 640), (2, 32, 1280, 1280)):
+            X = torch.randn(B, H, H, Cin, device="cuda").bfloat16(); W = (torch.randn(Cout, 9 * Cin, device="cuda") / math.sqrt(9 * Cin)).bfloat16()
+            Y = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.bfloat16); bias = torch.randn(Cout, device="cuda"); rvec = torch.randn(B, Cout, device="cuda")
+            R = torch.randn(B * H * H, Cout, device="cuda").bfloat16()
+            for name, b_, rv_, r_ in (("plain", None, None, None), ("bias", bias, None, None), ("bias+rowvec", bias, rvec, None), ("bias+residual", bias, None, R), ("all", bias, rvec, R)):
+                fn = lambda: L.ldx_op_conv3x3(p(X), Cin, p(W), B, H, H, Cin, Cout, 1, H, H, 0, p(b_), p(rv_), Cout, p(r_), Cout, p(Y), Cout, 0, st())
+                ms = timeit_graph(fn, 20)
+                print(f"conv B{B} {H}x{H} {Cin}->{Cout} {name:14s}: {ms * 1000:.1f} us  {2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9:.1f} TFLOP/s")
+    if what == "convk":    # fixed cost of a level-0 conv launch: time against Cin at fixed M = 32768, N = 320 (graph-timed)
+        for Cin in (64, 128, 192, 320, 640, 960):
+            B, H, Cout = 2, 128, 320
+            X = torch.randn(B, H, H, Cin, device="cuda").bfloat16(); W = (torch.randn(Cout, 9 * Cin, device="cuda") / math.sqrt(9 * Cin)).bfloat16()
+            Y = torch.empty(B * H * H, Cout, device="cuda", dtype=torch.bfloat16)
+            fn = lambda: L.ldx_op_conv3x3(p(X), Cin, p(W), B, H, H, Cin, Cout, 1, H, H, 0, None, None, 0, None, 0, p(Y), Cout, 0, st())
+            ms = timeit_graph(fn, 20)
+            print(f"conv B{B} {H}x{H} {Cin}->{Cout} K {9 * Cin}: {ms * 1000:.1f} us  {2.0 * B * H * H * Cout * 9 * Cin / ms / 1e9:.1f} TFLOP/s")
