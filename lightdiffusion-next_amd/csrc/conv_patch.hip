@@ -1,7 +1,7 @@
 // Patch-resident 3x3 convolution for narrow outputs (round 5): N = 32 / 64 / 128 output channels, stride 1, pad 1, optional nearest-resize gather.
 //
 // Why: ESRGAN's RRDBNet (UltimateSDUpscale/RDRB.py:80-205) is 345 convs of 64..192 -> 32 / 64 channels over a 512^2 tile, and the VAE decoder's last level
-// (VariationalAE.py:257-340) runs 128 -> 128 convs over 1024^2 .. 2048^2 pixels.  As an implicit GEMM with 128 x 32 .. 256 x 128 tiles every K-tile
+// (Decoder, VariationalAE.py:416-567: ResnetBlocks of AutoEncoders/ResBlock.py:341) runs 128 -> 128 convs over 1024^2 .. 2048^2 pixels.  As an implicit GEMM with 128 x 32 .. 256 x 128 tiles every K-tile
 // re-fetches the A rows of ONE tap: 9 x the input through the L2 -> LDS path, 32 - 85 flop per operand byte, and those launches sit at the ~24 B/clk/CU
 // that path delivers (ESRGAN 375 TFLOP/s = 26.9 ms per tile, VAE 128-channel convs 530 TFLOP/s; DESIGN r4 item 6).  Holding a whole 5-pixel-halo dense
 // block in LDS does not fit — but the 9 taps of ONE conv share one input patch, and that does:
