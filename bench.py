@@ -505,17 +505,8 @@ def main(argv=None):
         spec = ldx.weights.unet_state_dict_spec(cfg)
         tb0 = time.perf_counter()
         if world > 1 and not args.private_weights:
-            # ONE synthesis per node: local rank 0 writes the state dict under /dev/shm, the others map it (weights.publish_state_dict)
-            shm = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"ldx_sd_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}.bin")
-            if local_rank == 0:
-                sd = ldx.weights.publish_state_dict(spec, shm, seed=1234)
-            dist.barrier()
-            if local_rank != 0:
-                sd = ldx.weights.attach_state_dict(spec, shm)
-            dist.barrier()
-            if local_rank == 0:
-                os.unlink(shm)                                   # the mappings stay valid; nothing is left behind in /dev/shm
-            build["weights"] = "shared: local rank 0 synthesised, the others mapped /dev/shm"
+            # ONE synthesis per node (parallel.shared_state_dict: free-space check, agreed fall-back to private synthesis, tests/test_parallel_gloo.py)
+            sd, build["weights"] = ldx.parallel.shared_state_dict(dist, spec, rank, world, local_rank, local_world, seed=1234, tag=os.environ.get("MASTER_PORT", "0"))
         else:
             sd = ldx.weights.synth_state_dict(spec, seed=1234)
             build["weights"] = "private synthesis"

@@ -66,13 +66,17 @@ __global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
     __syncthreads();
     int t = st;
     t = max(0, min(t, p.n_sigmas - 1));
-    for (int j = tid; j < p.temb_dim; j += 256) p.temb_out[(long)b * p.temb_dim + j] = p.temb_table[(long)t * p.temb_dim + j];
+    // gridDim.y slices: every slice finds the same index, slice 0 writes the embedding row and the timestep, all of them share the emb_layers row copy
+    // (one workgroup per sample walked its 70 KB in 17 dependent 4-KiB rounds: 14 us of a 14 ms step)
+    const int part = blockIdx.y, nparts = gridDim.y;
+    if (part == 0)
+        for (int j = tid; j < p.temb_dim; j += 256) p.temb_out[(long)b * p.temb_dim + j] = p.temb_table[(long)t * p.temb_dim + j];
     if (p.emb_table) {                                   // emb_n % 4 == 0 (channel counts are multiples of 64)
         const float4* src = (const float4*)(p.emb_table + (long)t * p.emb_n);
         float4* dst = (float4*)(p.emb_out + (long)b * p.emb_n);
-        for (int j = tid; j < p.emb_n / 4; j += 256) dst[j] = src[j];
+        for (int j = tid + 256 * part; j < p.emb_n / 4; j += 256 * nparts) dst[j] = src[j];
     }
-    if (tid == 0 && p.t_out) p.t_out[b] = (float)t;
+    if (part == 0 && tid == 0 && p.t_out) p.t_out[b] = (float)t;
 }
 
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s) {
@@ -80,7 +84,7 @@ void launch_prep(const PrepArgs& a, DType dt, hipStream_t s) {
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
     if (dt == DT_BF16) hipLaunchKernelGGL((prep_image_kernel<__bf16>), dim3(grid), dim3(256), 0, s, a);
     else hipLaunchKernelGGL((prep_image_kernel<_Float16>), dim3(grid), dim3(256), 0, s, a);
-    if (a.temb_out) hipLaunchKernelGGL(prep_time_kernel, dim3(a.B), dim3(256), 0, s, a);
+    if (a.temb_out) hipLaunchKernelGGL(prep_time_kernel, dim3(a.B, a.emb_table ? 16 : 1), dim3(256), 0, s, a);
 }
 
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs p) {

@@ -275,3 +275,48 @@ def bind_rank_to_numa(local_rank: int, local_world: int):
     except Exception:
         pass
     return cpus
+
+
+def shared_state_dict(dist, spec, rank: int, world: int, local_rank: int, local_world: int, seed: int = 1234, dirs=("/dev/shm", "/tmp"), tag: str = "0"):
+    """ONE synthesis of the synthetic state dict per node (bench.py, N > 1): local rank 0 writes it under the first of `dirs` with enough free space
+    (weights.publish_state_dict), the other ranks of the node map it copy-on-write, local rank 0 unlinks it.  A tmpfs that is too small would kill the writer
+    with SIGBUS (not an exception) and leave the others waiting, so the free space is checked first, and EVERY rank learns the outcome (one
+    all_gather_object) before it touches the file; if anything fails, every rank of that node synthesises privately.  Returns (state dict, description)."""
+    import os
+    from . import weights
+    need = int(weights.state_dict_layout(spec)[1] * 1.02) + (1 << 20)
+    path, why, sd = None, "no directory with enough free space", None
+    if local_rank == 0:
+        for d in dirs:
+            try:
+                st = os.statvfs(d)
+                if os.path.isdir(d) and os.access(d, os.W_OK) and st.f_bavail * st.f_frsize >= need:
+                    path = os.path.join(d, f"ldx_sd_{tag}_{os.getppid()}_{rank}.bin")
+                    break
+            except OSError:
+                continue
+        if path:
+            try:
+                sd = weights.publish_state_dict(spec, path, seed=seed)
+            except Exception as e:                               # noqa: BLE001 - any failure means "fall back"
+                why, path, sd = f"{type(e).__name__}: {e}", None, None
+    got = [None] * world
+    dist.all_gather_object(got, (rank, local_rank, path, why))
+    node = rank // max(local_world, 1)
+    mine = [g for g in got if g[1] == 0 and g[0] // max(local_world, 1) == node]      # this node's local rank 0
+    path, why = (mine[0][2], mine[0][3]) if mine else (None, "no local rank 0 on this node")
+    failed = False
+    if path and local_rank != 0:
+        try:
+            sd = weights.attach_state_dict(spec, path)
+        except Exception as e:                                   # noqa: BLE001
+            sd, why, failed = None, f"attach failed: {e}", True
+    dist.barrier()                                               # everybody has mapped (or given up): the name can go, the mappings stay valid
+    if path and local_rank == 0:
+        try:
+            os.unlink(path)
+        except OSError:
+            pass
+    if sd is None:
+        return weights.synth_state_dict(spec, seed=seed), f"private synthesis (shared state dict unavailable: {why})"
+    return sd, f"shared: local rank 0 synthesised, the others mapped {os.path.dirname(path)}"

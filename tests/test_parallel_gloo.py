@@ -83,17 +83,16 @@ def _sd_worker(rank, world, port, path, q):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     cfg = ldx.UNetConfig.tiny(64, 128)
     spec = ldx.weights.unet_state_dict_spec(cfg)
-    sd = ldx.weights.publish_state_dict(spec, path, seed=1234) if rank == 0 else None
-    dist.barrier()
-    if rank != 0:
-        sd = ldx.weights.attach_state_dict(spec, path)
-    dist.barrier()
-    if rank == 0:
-        os.unlink(path)
+    # the function bench.py calls (free-space check, outcome agreed by all ranks, unlink); `path` is the directory to publish in — or one that does
+    # not exist, which must make BOTH ranks fall back to private synthesis instead of leaving rank 1 waiting for a file
+    sd, how = ldx.parallel.shared_state_dict(dist, spec, rank, world, rank, world, seed=1234, dirs=(path,), tag=str(port))
+    assert how.startswith("shared") == os.path.isdir(path), how
+    assert not [f for f in (os.listdir(path) if os.path.isdir(path) else []) if f.startswith("ldx_sd_")], "the published file must be unlinked"
     want = ldx.weights.synth_state_dict(spec, seed=1234)
     ok = set(sd) == set(want) and all(sd[k].dtype == want[k].dtype and torch.equal(sd[k], want[k]) for k in want)
     if rank != 0:                       # a rank's writes must stay private (copy-on-write mapping)
         sd[spec[0][0]].zero_()
+    ok = ok and (how.startswith("shared") or "unavailable" in how)
     dist.barrier()
     ok = ok and (rank != 0 or torch.equal(sd[spec[0][0]], want[spec[0][0]]))
     q.put((rank, bool(ok)))
@@ -101,14 +100,18 @@ def _sd_worker(rank, world, port, path, q):
     dist.destroy_process_group()
 
 
-def test_shared_state_dict_equals_private_synthesis(ldx, tmp_path):
-    """Round 5 (multi-GPU start-up): one synthesis per node through a mapped file == every rank's own synth_state_dict, bit for bit."""
+@pytest.mark.parametrize("usable", [True, False])
+def test_shared_state_dict_equals_private_synthesis(ldx, tmp_path, usable):
+    """Round 5 (multi-GPU start-up): one synthesis per node through a mapped file == every rank's own synth_state_dict, bit for bit; and when no
+    directory can take the file (usable = False) every rank falls back to its own synthesis — nobody waits for a file that will not come."""
     world = 2
     ctx = mp.get_context("spawn")
     q = ctx.SimpleQueue()
     port = _free_port()
-    path = str(tmp_path / "sd.bin")
-    procs = [ctx.Process(target=_sd_worker, args=(r, world, port, path, q)) for r in range(world)]
+    d = tmp_path / ("pub" if usable else "missing")
+    if usable:
+        d.mkdir()
+    procs = [ctx.Process(target=_sd_worker, args=(r, world, port, str(d), q)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get() for _ in procs)
@@ -116,7 +119,7 @@ def test_shared_state_dict_equals_private_synthesis(ldx, tmp_path):
         p.join(timeout=120)
         assert p.exitcode == 0
     assert res == {0: True, 1: True}
-    assert not os.path.exists(path)
+    path = str(tmp_path / "sd.bin")
     with pytest.raises(RuntimeError):                                   # a file of another model is refused, not mis-mapped
         spec = ldx.weights.unet_state_dict_spec(ldx.UNetConfig.tiny(64, 128))
         with open(path, "wb") as f:
