@@ -211,6 +211,19 @@ class CFGDenoiser:
         # this object's context lives in an engine-lifetime buffer that only _take_context() writes: its k|v projections may be cached across steps
         self._kw = {"ctx_cached": os.environ.get("LDX_CTX_CACHE", "1") != "0"} if hasattr(engine, "invalidate_context") else {}      # 0: recompute per call (A/B switch)
 
+    @staticmethod
+    def clear_pool(engine) -> int:
+        """Drop every device buffer CFGDenoisers have parked on `engine` (one set per (batch, shape) ever sampled, kept for the engine's lifetime so that
+        captured graphs are replayed across runs).  Denoisers created earlier keep working on the buffers they hold; new ones allocate afresh — and the
+        engine re-captures its graph for the new pointers.  Returns the number of entries dropped.  LDX_CFG_POOL=0 never shares in the first place."""
+        pool = getattr(engine, "__dict__", {}).get("_ldx_cfg_pool")
+        n = len(pool) if pool else 0
+        if pool:
+            pool.clear()
+        if n and hasattr(engine, "invalidate_context"):
+            engine.invalidate_context()
+        return n
+
     def _take_context(self):
         """Write this object's context into the engine's buffer and become its owner.  The engine caches the context's k|v projections per buffer
         (ldx_unet_context_cache: to_k / to_v of all cross-attentions are functions of the context alone — Attention.py:100-124 recomputes them every

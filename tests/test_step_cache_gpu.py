@@ -122,4 +122,10 @@ def test_cfg_denoisers_sharing_a_buffer_do_not_see_each_others_projections(eng, 
     del d1
     gc.collect()                                                 # the pool holds its owner weakly: nothing keeps a finished run's denoiser alive
     assert torch.equal(torch.cat(d2(x, torch.tensor(3.0))), want["2"])
+    # clear_pool: the parked buffers go, denoisers created before keep theirs, a new one allocates afresh and is still right
+    assert ldx.sampling.CFGDenoiser.clear_pool(e) > 0 and ldx.sampling.CFGDenoiser.clear_pool(e) == 0
+    d3 = ldx.sampling.CFGDenoiser(e, p1, n1, 7.0, 1, 16, 16)
+    assert d3.ctx.data_ptr() != d2.ctx.data_ptr()
+    assert torch.equal(torch.cat(d3(x, torch.tensor(3.0))), want["1"])
+    assert torch.equal(torch.cat(d2(x, torch.tensor(3.0))), want["2"])
     e.set_context_cache(False)
