@@ -579,7 +579,7 @@ bool conv_patch_ok(const GemmArgs& a) {
     if (nimg * a.Hin * a.Win * a.lda * 2 >= 0x7fffffffL) return false;      // 32-bit buffer offsets
     const long ntiles = nimg * (a.Hout / CP_TH) * (a.Wout / CP_TW);
     if (a.gn_partial && (a.N != 128 || a.gn_cpg != 4 || a.gn_G != 32 || a.gn_hw != a.Hout * a.Wout || a.gn_nchunk != (a.Hout / CP_TH) * (a.Wout / CP_TW))) return false;
-    return ntiles >= 256;               // at least one tile per CU
+    return ntiles >= (narrow ? 64 : 256);      // at least one tile per CU; the 3 / 4-channel tails win from 64 tiles on (UNet out conv at 128^2 x 2: 39 -> see profiles/r05)
 }
 // gemm_gn_fuse's question for this kernel: chunks per image if the epilogue can produce the consumer GroupNorm's statistics, else 0
 int conv_patch_gn_chunks(const GemmArgs& a, int HW, int G) {
