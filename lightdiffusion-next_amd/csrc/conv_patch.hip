@@ -69,6 +69,19 @@ static __device__ __forceinline__ void cp_wait_n(int n) {
         : "=&s"(t) : "s"(n) : "vcc", "scc", "memory");
 }
 
+// Residual operands of one output row for all NJ column tiles, as UNCONDITIONAL 8-byte loads issued together (a null operand reads the weights instead and
+// is dropped by a select).  Written per (row, column tile) behind `if (p.R)`, hipcc emitted load + s_waitcnt vmcnt(0) pairs: up to 32 HBM latencies in a
+// row per tile (the same pattern as the split-K reduce launches) — ESRGAN's conv5 (two residuals) and the VAE's conv2 paid them on every tile.
+template <typename T, int NJ>
+static __device__ __forceinline__ void cp_load_residuals(const GemmArgs& p, const long m, const int g4, uint2 (&r1)[NJ], uint2 (&r2)[NJ]) {
+    const char* z = (const char*)p.W;
+    const char* b1 = p.R ? (const char*)((const T*)p.R + m * p.ldr + 4 * g4) : z;
+    const char* b2 = p.R2 ? (const char*)((const T*)p.R2 + m * p.ldr2 + 4 * g4) : z;
+    const int s1 = p.R ? 32 : 0, s2 = p.R2 ? 32 : 0;      // 16 columns = 32 bytes per column tile
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) { r1[j] = *(const uint2*)(b1 + j * s1); r2[j] = *(const uint2*)(b2 + j * s2); }
+}
+
 constexpr int CP_TH = 16, CP_TW = 32, CP_PW = CP_TW + 2, CP_PIX = (CP_TH + 2) * CP_PW;     // 612 patch pixels
 constexpr int CP_PP = (CP_PIX * 4 + 63) / 64;                                             // 39 pieces of 64 slots per channel chunk
 constexpr int CP_PATCH = CP_PP * 1024;
@@ -291,6 +304,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const GemmArgs p, co
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = ((long)b * p.Hout + y0 + wrow + r) * p.Wout + x0 + 16 * half + l15;
+            uint2 q1[NJ], q2[NJ];
+            cp_load_residuals<T, NJ>(p, m, g4, q1, q2);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = j * 16 + 4 * g4;
@@ -301,8 +316,8 @@ __global__ __launch_bounds__(512, 1) void conv_patch_kernel(const GemmArgs p, co
                     for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
                 }
                 if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                if (Rp) { float rr[4]; unpack4<T>(*(const uint2*)(Rp + m * p.ldr + n), rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
-                if (p.R2) { float rr[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + m * p.ldr2 + n), rr);
+                if (Rp) { float rr[4]; unpack4<T>(q1[j], rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                if (p.R2) { float rr[4]; unpack4<T>(q2[j], rr);
                             v[0] = fmaf(v[0], p.oscale2, rr[0]); v[1] = fmaf(v[1], p.oscale2, rr[1]); v[2] = fmaf(v[2], p.oscale2, rr[2]); v[3] = fmaf(v[3], p.oscale2, rr[3]); }
                 if (Cp && !(abl & 8)) *(uint2*)(Cp + m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                 if (p.Cf) *(float4*)(p.Cf + m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
@@ -528,6 +543,8 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
             const long m = ((long)b * p.Hout + y0 + wrow + r) * p.Wout + x0 + 16 * half + l15;
+            uint2 q1[NJ], q2[NJ];
+            if constexpr (NJ > 1) cp_load_residuals<T, NJ>(p, m, g4, q1, q2);
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = j * 16 + 4 * g4;
@@ -553,8 +570,8 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
                     for (int q = 0; q < 4; ++q) v[q] = v[q] > 0.f ? v[q] : 0.2f * v[q];
                 }
                 if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                if (Rp) { float rr[4]; unpack4<T>(*(const uint2*)(Rp + m * p.ldr + n), rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
-                if (p.R2) { float rr[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + m * p.ldr2 + n), rr);
+                if (Rp) { float rr[4]; unpack4<T>(q1[j], rr); v[0] += rr[0]; v[1] += rr[1]; v[2] += rr[2]; v[3] += rr[3]; }
+                if (p.R2) { float rr[4]; unpack4<T>(q2[j], rr);
                             v[0] = fmaf(v[0], p.oscale2, rr[0]); v[1] = fmaf(v[1], p.oscale2, rr[1]); v[2] = fmaf(v[2], p.oscale2, rr[2]); v[3] = fmaf(v[3], p.oscale2, rr[3]); }
                 if (Cp && !(abl & 8)) *(uint2*)(Cp + m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
                 if (p.Cf) *(float4*)(p.Cf + m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
