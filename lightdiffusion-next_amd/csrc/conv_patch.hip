@@ -383,24 +383,48 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
         // ---- patch loader: chunk stream (tile, kc) in order, PR - 1 chunks ahead of the consumers; all 39 pieces of a chunk from this wave
         const cp_i32x4 rA = cp_srd(p.A, (((long)nimg * p.Hin * p.Win - 1) * p.lda + Cin) * 2);
         const float rs_y = p.resize ? (float)p.Hin / (float)p.Hv : 1.f, rs_x = p.resize ? (float)p.Win / (float)p.Wv : 1.f;
-        int pv[CP_PP];                   // per-lane source offsets of the tile being issued (slot q = 64 piece + lane -> pixel q >> 2 = 34 Y + X, position q & 3)
+        // Per-lane source offsets (slot q = 64 piece + lane -> pixel q >> 2 = 34 Y + X, position q & 3).  Without a resize they are the sum of a part that does
+        // not depend on the tile — pv[i] = (Y Win + X) lda 2 + 16 octet, computed ONCE — and the patch origin (a scalar, passed as the DMA's scalar offset); only tiles on the image
+        // border need per-lane in-bounds tests, made once per such tile.  (Recomputing all 39 offsets per tile cost the loader, and through the
+        // step barrier everybody, 3.7 us per tile: 51.2 -> 36.6 us on a 4-tile launch, profiles/r05/conv_patch_ablations.txt.)  With a resize gather the
+        // source pixel is not separable and the offsets are recomputed per tile as before.
+        int pv[CP_PP];
+        int sbase = 0, ty0 = 0, tx0 = 0;
+        bool border = false, pv_rel = false;
         auto patch_offsets = [&](int it) __attribute__((always_inline)) {
             int b, y0, x0;
             tile_of(it < ntl ? it : 0, b, y0, x0);
+            if (!p.resize) {
+                sbase = ((b * p.Hin + y0 - 1) * p.Win + x0 - 1) * p.lda * 2;      // the patch's first pixel (negative only on border tiles, which add it per lane)
+                ty0 = y0 - 1; tx0 = x0 - 1;
+                border = y0 == 0 || x0 == 0 || y0 + CP_TH >= p.Hv || x0 + CP_TW >= p.Wv;
+                if (border || !pv_rel) {             // pv holds the tile-independent offsets (interior tiles) or a border tile's masked absolute ones: one
+                    int ln;                          // array, rebuilt only on a border tile (a fifth of the tiles of a 512^2 image) and on the way back
+                    asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));      // (opaque lane id: otherwise the tile-independent halves are hoisted and spilled)
+                    int Y = 0, X = ln >> 2;
+#pragma unroll
+                    for (int i = 0; i < CP_PP; ++i) {
+                        if (i) { X += 16; if (X >= CP_PW) { X -= CP_PW; ++Y; } }
+                        const int oct = (ln & 3) ^ (((X >> 2) & 1) << 1);
+                        const int rel = ((Y * p.Win + X) * p.lda + oct * 8) * 2;
+                        const int vy = ty0 + Y, vx = tx0 + X;
+                        const bool ok = i * 16 + (ln >> 2) < CP_PIX && (!border || (vy >= 0 && vy < p.Hv && vx >= 0 && vx < p.Wv));
+                        pv[i] = ok ? (border ? rel + sbase : rel) : OOB;
+                    }
+                    pv_rel = !border;
+                }
+                return;
+            }
             int ln;                          // opaque lane id: the per-piece (Y, X) chain is recomputed per tile, not hoisted out of the tile loop and spilled
             asm volatile("v_mov_b32 %0, %1" : "=v"(ln) : "v"(lane));
-            int Y = 0, X = ln >> 2;          // pixel of piece 0; every piece is 16 pixels further (no division: this runs once per tile on the critical path)
+            int Y = 0, X = ln >> 2;          // pixel of piece 0; every piece is 16 pixels further
 #pragma unroll
             for (int i = 0; i < CP_PP; ++i) {
                 if (i) { X += 16; if (X >= CP_PW) { X -= CP_PW; ++Y; } }
                 const int P = i * 16 + (ln >> 2);
                 const int oct = (ln & 3) ^ (((X >> 2) & 1) << 1);
                 const int vy = y0 - 1 + Y, vx = x0 - 1 + X;
-                int sy = vy, sx = vx;
-                if (p.resize) {
-                    sy = min((int)floorf((float)vy * rs_y), p.Hin - 1);
-                    sx = min((int)floorf((float)vx * rs_x), p.Win - 1);
-                }
+                const int sy = min((int)floorf((float)vy * rs_y), p.Hin - 1), sx = min((int)floorf((float)vx * rs_x), p.Win - 1);
                 const bool in = P < CP_PIX && vy >= 0 && vy < p.Hv && vx >= 0 && vx < p.Wv;
                 pv[i] = in ? (((b * p.Hin + sy) * p.Win + sx) * p.lda + oct * 8) * 2 : OOB;
             }
@@ -413,12 +437,22 @@ __global__ __launch_bounds__(640, 1) void conv_patch_ws_kernel(const GemmArgs p,
         auto issue_chunk = [&]() __attribute__((always_inline)) {
             const unsigned dst = lds_base + pslot_in * CP_PATCH;
             if (!(abl & 1)) {
+                if (p.resize) {
 #pragma unroll
-                for (int i = 0; i < CP_PP; ++i) cp_dma16(rA, pv[i], kc_in * 64, dst + i * 1024);
+                    for (int i = 0; i < CP_PP; ++i) cp_dma16(rA, pv[i], kc_in * 64, dst + i * 1024);
+                } else {
+                    if (!border) {                           // two loops, not a test per piece: hipcc if-converted the per-piece form and every tile paid the masks
+#pragma unroll
+                        for (int i = 0; i < CP_PP; ++i) cp_dma16(rA, pv[i], sbase + kc_in * 64, dst + i * 1024);
+                    } else {
+#pragma unroll
+                        for (int i = 0; i < CP_PP; ++i) cp_dma16(rA, pv[i], kc_in * 64, dst + i * 1024);
+                    }
+                }
             }
             issued += CP_PP;
             pslot_in = pslot_in + 1 == PR ? 0 : pslot_in + 1;
-            if (++kc_in == nkc) { kc_in = 0; ++it_in; if (it_in < ntl) patch_offsets(it_in); }
+            if (++kc_in == nkc) { kc_in = 0; ++it_in; if (it_in < ntl && !(abl & 32)) patch_offsets(it_in); }
         };
 #pragma unroll
         for (int c = 0; c < PR - 1; ++c) { issue_chunk(); pq[c] = issued; }      // nkc >= 2 >= PR - 1: all of tile 0
@@ -614,7 +648,7 @@ static void launch_conv_patch_t(const GemmArgs& a, hipStream_t s) {
     const int ntiles = (a.M / (a.Hout * a.Wout)) * (a.Hout / CP_TH) * (a.Wout / CP_TW);
     static const int ncu = [] { int dev = 0, n = 256; if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev); return n > 0 ? n : 256; }();
     const int grid = ntiles < ncu ? ntiles : ncu;
-    static const int abl = getenv("LDX_CP_ABL") ? atoi(getenv("LDX_CP_ABL")) : 0;      // timing ablations (wrong results): 1 no patch loads, 2 no weight loads, 4 no MFMAs (N = 32), 8 no stores, 16 no fragment reads (N = 32)
+    static const int abl = getenv("LDX_CP_ABL") ? atoi(getenv("LDX_CP_ABL")) : 0;      // timing ablations (wrong results): 1 no patch loads, 2 no weight loads, 4 no MFMAs (N = 32), 8 no stores, 16 no fragment reads (N = 32), 32 no per-tile offset recomputation (loader-wave kernel)
     hipLaunchKernelGGL((conv_patch_kernel<T, NJ, PR, RW>), dim3(grid), dim3(512), lds, s, a, ntiles, abl);
 }
 

@@ -8,10 +8,12 @@ L = ldx.lib.load()
 p = lambda t: None if t is None else C.c_void_p(t.data_ptr())
 st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
 SHAPES = [(512, 512, 64, 32, 192), (512, 512, 128, 32, 192), (512, 512, 192, 32, 192), (512, 512, 192, 64, 192), (512, 512, 64, 64, 64),
-          (2048, 2048, 64, 64, 64), (1024, 1024, 128, 128, 128), (1024, 1024, 256, 128, 256), (2048, 2048, 128, 128, 128)]
+          (2048, 2048, 64, 64, 64), (1024, 1024, 128, 128, 128), (1024, 1024, 256, 128, 256), (2048, 2048, 128, 128, 128),
+          (256, 512, 64, 32, 192), (1024, 512, 64, 32, 192), (2048, 512, 64, 32, 192), (256, 512, 192, 32, 192), (1024, 512, 192, 32, 192)]      # 9-13: tiles per workgroup 1 / 4 / 8: fixed cost per launch vs cost per tile
 only = int(sys.argv[1]) if len(sys.argv) > 1 else -1
+lo = int(sys.argv[2]) if len(sys.argv) > 2 else -1
 for idx, (H, W, Cin, Cout, ld) in enumerate(SHAPES):
-    if only >= 0 and idx != only: continue
+    if only >= 0 and idx != only and not (lo >= 0 and only <= idx <= lo): continue
     X = torch.randn(1, H, W, ld, device="cuda").bfloat16()
     Wp = (torch.randn(Cout, 9 * Cin, device="cuda") / math.sqrt(9 * Cin)).bfloat16()
     bias = torch.randn(Cout, device="cuda")
