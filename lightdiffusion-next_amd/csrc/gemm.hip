@@ -715,7 +715,7 @@ bool gemm_sk_fixup(const GemmArgs& a) {
 
 void gemm_gn_tile_check(const GemmArgs& a, int BM, int BN, int S) {
     if (!a.gn_partial || S > 1 || a.gn_cpg <= 0) return;       // split-K: the reduce launch owns the statistics and checks its own geometry
-    if (a.gn_hw % BM || a.gn_nchunk != a.gn_hw / BM || BN % a.gn_cpg || BN > 160) {
+    if (a.gn_hw % BM || a.gn_nchunk != a.gn_hw / BM || BN % a.gn_cpg || (BN > 160 && !(BM == 256 && BN <= 256 && a.N % BN == 0 && a.M % BM == 0))) {      // > 160: the ping-pong tiles' column-major stage
         fprintf(stderr, "ldx: GroupNorm-statistics geometry mismatch: planned for %d chunks of an image of %d rows, %d channels per group; launching %d x %d tiles\n",
                 a.gn_nchunk, a.gn_hw, a.gn_cpg, BM, BN);
         abort();
@@ -755,7 +755,9 @@ int gemm_gn_fuse(GemmArgs& a, int HW, int G, int max_chunks) {
     else if (t.bm == 64) { bm = 64; bn = t.bn == 160 ? 160 : 64; }
     else if (t.bn == 160) { bm = 128; bn = 160; }
     else { bm = 128; bn = 128; }
-    if (bn > 160 || bn % cpg || HW % bm || (bn / cpg) * 2 > 256) return 0;          // epilogue support (gemm_common.h GNS); groups must not straddle tile columns, tiles must not straddle images
+    static const bool wide_off = getenv("LDX_GN_FUSE_WIDE") && atoi(getenv("LDX_GN_FUSE_WIDE")) == 0;
+    const bool wide_ok = bm == 256 && bn > 160 && bn <= 256 && !wide_off && a.N % bn == 0 && a.M % bm == 0 && !a.geglu;      // the column-major output stage of the ping-pong tiles (gemm_common.h GNW): whole tiles only
+    if ((bn > 160 && !wide_ok) || bn % cpg || HW % bm || (bn / cpg) * 2 > 256) return 0;          // epilogue support (gemm_common.h GNS / GNW); groups must not straddle tile columns, tiles must not straddle images
     const int nchunk = HW / bm;
     if (nchunk > max_chunks) return 0;
     a.gn_cpg = cpg; a.gn_G = G; a.gn_hw = HW; a.gn_nchunk = nchunk;

@@ -193,6 +193,71 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
     // cannot afford without scratch (gemm_gn_fuse never selects those).
     constexpr bool GNS = GNOK && NJ <= 5 && !LNF;
     const bool gn = GNS && p.gn_partial != nullptr;
+    // Wide tiles (192..256 columns, NJ = 6..8; round 5): the statistics come from a COLUMN-major output stage instead — for each column tile the lane
+    // walks its MI rows, stores them and adds the rounded values in-lane, so an accumulator dies as soon as its column tile is done and nothing is parked
+    // (same sums in the same order as the path above: in-lane over i, DPP over the 16 lanes of a column, LDS over the wave rows).  gemm_gn_fuse only plans
+    // it for whole tiles (M % BM == 0 within an image, N % BN == 0), so there is no ragged path here.  The VAE's 256 / 512-channel convs are the users.
+    constexpr bool GNW = GNOK && NJ > 5 && NJ <= 8 && !LNF && NR == 1;
+    if constexpr (GNW) if (p.gn_partial != nullptr) {
+        extern __shared__ __attribute__((aligned(16))) char smem_epw[];
+        float* red = (float*)smem_epw;                  // [WM][BN][2]; the operand tiles are dead behind the barrier
+        __syncthreads();
+        int bi[MI];
+#pragma unroll
+        for (int i = 0; i < MI; ++i) bi[i] = (m0 + wm * (BM / WM) + i * 16 + l15) / p.rows_per_batch;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
+            float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+            const float4 bz = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int i = 0; i < MI; ++i) {
+                const long m = m0 + wm * (BM / WM) + i * 16 + l15;
+                float v[4] = {acc[i][j][0] + bz.x, acc[i][j][1] + bz.y, acc[i][j][2] + bz.z, acc[i][j][3] + bz.w};
+                if (p.rowvec) { const float4 b = *(const float4*)(p.rowvec + (long)bi[i] * p.rowvec_ld + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.act == 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                } else if (p.act == 3) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                }
+                if (p.gate) { const float4 b = *(const float4*)(p.gate + (long)bi[i] * p.gate_ld + n); v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
+                if (Rp) { float r[4]; unpack4<T>(*(const uint2*)(Rp + m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                if (p.R2) { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + m * p.ldr2 + n), r);
+                            v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) { const float xr = to_f32(from_f32<T>(v[r])); gs[r] += xr; gq[r] = fmaf(xr, xr, gq[r]); }
+                if (Cp) *(uint2*)(Cp + m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                if (p.Cf) *(float4*)(p.Cf + m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { gs[r] = row16_sum(gs[r]); gq[r] = row16_sum(gq[r]); }
+            if (l15 == 0) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int col = wn * (BN / 2) + j * 16 + 4 * g4 + r;
+                    red[(wm * BN + col) * 2 + 0] = gs[r];
+                    red[(wm * BN + col) * 2 + 1] = gq[r];
+                }
+            }
+        }
+        __syncthreads();
+        const int cpg = p.gn_cpg, tid = threadIdx.x;
+        if (tid < (BN / cpg) * 2) {
+            const int gl = tid >> 1, st = tid & 1, nc0 = n0 + gl * cpg;
+            float a = 0.f;
+            for (int w = 0; w < WM; ++w)
+                for (int c = 0; c < cpg; ++c) a += red[(w * BN + gl * cpg + c) * 2 + st];
+            const int b = m0 / p.gn_hw, chunk = (m0 - b * p.gn_hw) / BM;
+            p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + nc0 / cpg) * 2 + st] = a;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + l15;
