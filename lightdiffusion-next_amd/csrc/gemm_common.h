@@ -190,7 +190,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
     T* __restrict__ Cp = (T*)p.C;
     // GroupNorm statistics of the stored tile (GemmArgs::gn_partial).  Compiled in only for tiles up to 160 columns: keeping the rounded outputs in
     // the accumulator registers makes all of them live through the output stage, which the 192..256-wide ping-pong tiles (128 accumulators, 212 VGPRs)
-    // cannot afford without scratch (gemm_gn_fuse never selects those).
+    // cannot afford without scratch — those take the column-major stage below (GNW).
     constexpr bool GNS = GNOK && NJ <= 5 && !LNF;
     const bool gn = GNS && p.gn_partial != nullptr;
     // Wide tiles (192..256 columns, NJ = 6..8; round 5): the statistics come from a COLUMN-major output stage instead — for each column tile the lane
