@@ -353,10 +353,19 @@ __global__ __launch_bounds__(256) void mx_vt_quant_kernel(const MxVtArgs p) {
     const int tid = threadIdx.x;
     const int blk = blockIdx.x, h = blockIdx.y, b = blockIdx.z;
     const T* __restrict__ V = (const T*)p.V + (long)b * p.L * p.ldv + h * AM_D;
-    for (int i = tid; i < 128 * 16; i += 256) {
-        const int row = i >> 4, ch = i & 15, tok = blk * 128 + row;
-        const uint4 u = tok < p.L ? *(const uint4*)(V + (long)tok * p.ldv + ch * 8) : make_uint4(0, 0, 0, 0);
-        *(uint4*)(&sv[row][ch * 8]) = u;
+    {   // the block's 128 x 128 values: eight UNCONDITIONAL 16-byte loads per thread issued together (a token past L re-reads the last one and is zeroed
+        // by a select; behind `tok < L ? load : 0` hipcc emitted one load + wait per iteration: eight memory latencies in a row per workgroup)
+        uint4 u[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, row = i >> 4, ch = i & 15, tok = blk * 128 + row;
+            u[j] = *(const uint4*)(V + (long)(tok < p.L ? tok : p.L - 1) * p.ldv + ch * 8);
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int i = tid + 256 * j, row = i >> 4, ch = i & 15, tok = blk * 128 + row;
+            *(uint4*)(&sv[row][ch * 8]) = tok < p.L ? u[j] : make_uint4(0, 0, 0, 0);
+        }
     }
     __syncthreads();
     const int d = tid & 127, s = tid >> 7;                    // this thread: column d, 64-key step s of the block
