@@ -1,4 +1,5 @@
-// Patch-resident 3x3 convolution for narrow outputs (round 5): N = 32 / 64 / 128 output channels, stride 1, pad 1, optional nearest-resize gather.
+// Patch-resident 3x3 convolution for narrow outputs (round 5): N = 32 / 64 / 128 output channels (and the 3 / 4-channel tails conv_last / conv_out / the UNet's out conv
+// as one 16-column tile whose missing weight rows read as zeros), stride 1, pad 1, optional nearest-resize gather.
 //
 // Why: ESRGAN's RRDBNet (UltimateSDUpscale/RDRB.py:80-205) is 345 convs of 64..192 -> 32 / 64 channels over a 512^2 tile, and the VAE decoder's last level
 // (Decoder, VariationalAE.py:416-567: ResnetBlocks of AutoEncoders/ResBlock.py:341) runs 128 -> 128 convs over 1024^2 .. 2048^2 pixels.  As an implicit GEMM with 128 x 32 .. 256 x 128 tiles every K-tile
@@ -16,6 +17,8 @@
 // Sizing: a load issued under load lands ~1.1 us later (MI355X_MICROARCH.md "ldsdma-fill"), a step is 768 (N = 32) .. 3072 (N = 128) MFMA cycles per SIMD,
 // so N = 32 keeps 5 weight stages + 2 patch chunks in flight (PR 3, RW 6), N = 64: 5 + 1 (PR 2, RW 6), N = 128: 2 + 1 (PR 2, RW 3) — 150-155 KiB of LDS each.
 // (The first version — 16 x 16 tiles, 4 waves, two workgroups per CU, one weight stage ahead — ran at a third of its MFMA time: ESRGAN 26.6 -> 15.8 ms.)
+// What bounds it now (profiles/r05/conv_patch_ablations.txt): a CU pulls ~57 KB/us through its load path — one chunk of N = 32 (39 KB of patch + 18 KB of weights)
+// per microsecond against 0.96 us of MFMA time for its three steps — plus ~4 us per tile of output stage, first-load latency and barriers.
 //
 // LDS layouts are chosen through the DMA's per-lane SOURCE address (the destination of a piece is always 64 consecutive 16-B slots):
 //   patch slot (P = 34 Y + X, pos) holds channel octet  pos ^ 2 ((X >> 2) & 1)  — the 16 lanes of a ds_read_b128 group (pixels X = 16 half + l15 + kx,
