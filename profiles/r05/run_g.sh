@@ -1,3 +1,4 @@
-mkdir -p gpurun_out/r05g
-python -m pytest tests/test_attn_mx_gpu.py -m gpu -x -q -s > gpurun_out/r05g/t_attn_mx.log 2>&1; echo "attn_mx rc $?"
-grep -E "attention_fp8|rope_mx|flux shape|passed|failed|Error|assert" gpurun_out/r05g/t_attn_mx.log | head -40
+timeout 900 python -m pytest tests/test_pingpong_gpu.py tests/test_ops_gpu.py -m gpu -x -q -k "forced or geglu" 2>&1 | tail -2
+echo default; python profiles/kprobe.py geglu 2>&1 | grep "^gemm"
+echo forced256256; LDX_GEMM_TILE=256256 python profiles/kprobe.py geglu 2>&1 | grep "^gemm"
+echo forced256128; LDX_GEMM_TILE=256128 python profiles/kprobe.py geglu 2>&1 | grep "^gemm"
