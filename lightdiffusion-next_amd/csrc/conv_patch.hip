@@ -77,7 +77,6 @@ static __device__ __forceinline__ void cp_wait_n(int n) {
 // row per tile (the same pattern as the split-K reduce launches) — ESRGAN's conv5 (two residuals) and the VAE's conv2 paid them on every tile.
 template <typename T, int NJ>
 static __device__ __forceinline__ void cp_load_residuals(const GemmArgs& p, const long m, const int g4, uint2 (&r1)[NJ], uint2 (&r2)[NJ]) {
-    if (!p.R && !p.R2) return;               // (one uniform branch per row: a conv without residuals must not pay 2 NJ loads behind the DMAs in flight)
     const char* z = (const char*)p.W;
     const char* b1 = p.R ? (const char*)((const T*)p.R + m * p.ldr + 4 * g4) : z;
     const char* b2 = p.R2 ? (const char*)((const T*)p.R2 + m * p.ldr2 + 4 * g4) : z;
