@@ -149,6 +149,20 @@ int ldx_unet_denoise_concat(ldx_engine* e, const float* x_nchw, const float* sig
  * ldx_unet_denoise on the concatenated inputs (bit-identical); replaces two device copies and a fill per sampler step. */
 int ldx_unet_denoise_cfg(ldx_engine* e, const float* x_nchw, float sigma, const float* ctx,
                          int B, int h, int w, int M, float* out_nchw, void* stream);
+/* The same with the timestep index supplied by the caller.  ModelSamplingDiscrete.timestep (sample/sampling.py:309-320, called from
+ * BaseModel.apply_model, ModelBase.py:112) is INTEGER work: argmin_k |log(sigma) - log_sigmas[k]|.  The device lookup (ldx_unet_denoise*,
+ * ldx_unet_timestep) runs the GPU's logf, which may differ from the host's log in the last bit — at a near-tie (sigma at the geometric midpoint of two
+ * table entries, e.g. the `normal` scheduler's fractional timesteps) that picks the other index.  Where sigma is a host scalar (every sampler
+ * loop) the host side therefore evaluates the reference's own torch expression and passes the result here: bit-exact by construction.
+ * t_index in [0, n_sigmas); t_index < 0 = ldx_unet_denoise_cfg (device lookup). */
+int ldx_unet_denoise_cfg_t(ldx_engine* e, const float* x_nchw, float sigma, int t_index, const float* ctx,
+                           int B, int h, int w, int M, float* out_nchw, void* stream);
+/* ldx_unet_denoise with per-sample timestep indices from the caller: t_index [B2] fp32 DEVICE array (integer-valued), same reasoning. */
+int ldx_unet_denoise_t(ldx_engine* e, const float* x_nchw, const float* sigma, const float* t_index, const float* ctx,
+                       int B2, int h, int w, int M, float* out_nchw, void* stream);
+/* The device's sigma -> timestep lookup alone (the device function the boundary kernel of ldx_unet_denoise* runs): sigma [n] fp32 and
+ * t_out [n] int32 are DEVICE arrays.  For tests of the index as an integer (tests/test_timestep_gpu.py). */
+int ldx_unet_timestep(ldx_engine* e, const float* sigma, int n, int32_t* t_out, void* stream);
 /* Context cache for a sampling run.  The reference recomputes to_k(context) / to_v(context) of all 16 cross-attentions in every step
  * (CrossAttention.forward, src/Attention/Attention.py:100-124, called from transformer.py:186-245) although `c_crossattn` is the same tensor content
  * for every step of a run (calc_cond_batch rebuilds it from the same conditioning, cond/cond.py:150-288).  enable = 1: the CALLER PROMISES that the
@@ -162,8 +176,20 @@ int ldx_unet_context_cache(ldx_engine* e, int enable);
 int ldx_unet_forward(ldx_engine* e, const float* x_nchw, const float* timesteps, const float* ctx,
                      int B2, int h, int w, int M, float* out_nchw, void* stream);
 /* Number of kernel launches in the current plan, algorithmic FLOPs of one forward at the planned shape
- * (2*MACs of every Linear/Conv + 4*B*H*N*M*D per attention), arena bytes. */
+ * (2*MACs of every Linear/Conv + 4*B*H*N*M*D per attention), arena bytes.  STEADY-STATE numbers: while the context cache is on
+ * (ldx_unet_context_cache) the context's 16-bit copy and k|v projections are not part of them (they run once per context, not per step). */
 int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes);
+/* Shared CFG prefix.  calc_cond_batch evaluates [uncond; cond] over cat([x] * 2) and cat([sigma] * 2) (cond/cond.py:186-226): until the context enters at the
+ * first cross-attention (input_blocks.1.1.transformer_blocks.0.attn2 in SD1.5) both halves of the batch hold IDENTICAL values — conv_in, the first
+ * ResBlock, norm / proj_in, norm1, q|k|v, the first self-attention and its to_out compute every number twice.  ldx_unet_denoise_cfg* (the one entry
+ * point that KNOWS the halves share x and sigma) plans those ops on one half and copies the results into the other half's rows where the first
+ * cross-attention and the skip connections read them; the outputs equal the concatenated ldx_unet_denoise call up to the summation order of
+ * GroupNorm statistics (tile shapes follow the row count).  enable = 0: every op on the full batch (bit-identical to the concatenated call).
+ * Default on (environment LDX_CFG_SHARE=0 switches the default off). */
+int ldx_unet_cfg_share(ldx_engine* e, int enable);
+/* FLOPs of the current plan as EXECUTED in steady state, and the part of ldx_plan_info's algorithmic count that the shared CFG prefix does not
+ * execute (algorithmic = executed + shared).  Roofline fractions are quoted on the executed number. */
+int ldx_plan_flops(ldx_engine* e, double* executed, double* shared);
 /* Memory behaviour: an engine keeps the launch plan, arena and captured graph of its CURRENT input shape plus up to four earlier
  * shapes (the multi-scale samplers and HiresFix alternate between resolutions; Flux plans are per (B, h, w, prompt length)).  Each
  * cached plan holds its own arena; the cache is trimmed oldest-first to at most 4 entries and LDX_PLAN_CACHE_GIB (default 16) GiB. */
@@ -238,9 +264,10 @@ int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses);
  * quantised once in ldx_finalize, activations per forward); everything else stays 16-bit.  Call before ldx_finalize;
  * needs hidden_size % 128 == 0 and mlp_hidden % 128 == 0.  The reference runs Flux from Q8_0 weights (also 32-element
  * blocks, src/Quantize/Quantizer.py:94-112) dequantised to 16-bit, i.e. W8A16; this mode is W8A8.
- * enable = 1 (round 5): ... and, at head dim 128, QK^T and PV of the joint attention on the block-scaled 32x32x64 MFMA as well (the rule of
- * ldx_op_attention_fp8 below: Q / K quantised by the QKNorm + RoPE kernel, V by a transposing quantiser, P rounded to e4m3) — the whole block is fp8 MFMA.
- * enable = 2: the linears only; attention stays 16-bit (what "fp8" meant through round 4; kept for A/B runs). */
+ * enable = 1 (2 is an alias): the linears only; attention stays 16-bit.
+ * enable = 3 (explicit opt-in; a DIFFERENT, less precise workload than mode 1): ... and, at head dim 128, QK^T and PV of the joint attention on the
+ * block-scaled 32x32x64 MFMA as well (the rule of ldx_op_attention_fp8 below: Q / K quantised by the QKNorm + RoPE kernel, V by a transposing quantiser,
+ * P rounded to e4m3) — the whole block is fp8 MFMA.  (Round 5 had this behind enable = 1; callers of mode 1 get the linears-only arithmetic back.) */
 int ldx_flux_set_fp8(ldx_engine* e, int enable);
 
 /* ---- T5-XXL text encoder (Flux conditioning) ---------------------------------------------------- */

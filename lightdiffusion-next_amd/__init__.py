@@ -19,4 +19,4 @@ VAEEngine = VAEDecoderEngine      # the same engine encodes when encoder.* weigh
 from .weights import VAEConfig, CLIPConfig, FluxConfig, T5Config, ESRGANConfig  # noqa: F401
 from .hook import LdxUNetPatch, LdxFluxPatch  # noqa: F401
 from . import prompt  # noqa: F401
-from . import sampling, parallel, checkpoint, gguf_loader  # noqa: F401
+from . import sampling, parallel, checkpoint  # noqa: F401

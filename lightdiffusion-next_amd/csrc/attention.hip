@@ -1025,6 +1025,15 @@ static AttnSwitches read_attn_switches() {
 static AttnSwitches g_attn_sw = read_attn_switches();
 void reload_dispatch_env() { g_attn_sw = read_attn_switches(); }
 
+// which kernel family launch_attention() takes for `a` (planner / profile labels): 3 attn512, 1 attn40p, 2 attn128p, 0 the generic dispatch (attn32g / attn32 / attn)
+int attention_dispatch_class(const AttnArgs& a) {
+    const AttnSwitches& w = g_attn_sw;
+    if (attn512_ok(a)) return 3;
+    if (w.pipe40 && attn_pipe_ok(a) && (long)(a.Nq / 256) * a.H * a.B >= w.minwg40) return 1;
+    if (w.pipe128 && attn_pipe128_ok(a) && (long)(a.Nq / 256) * a.H * a.B >= w.minwg128) return 2;
+    return 0;
+}
+
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s) {
     if (a.Nq <= 0 || a.B <= 0) return;
     const AttnSwitches& w = g_attn_sw;

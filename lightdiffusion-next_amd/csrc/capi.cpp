@@ -185,8 +185,9 @@ int ldx_flux_set_fp8(ldx_engine* e, int enable) {
     GUARD_BEGIN
     if (!e || e->impl->kind != KIND_FLUX) { set_error("ldx_flux_set_fp8: not a Flux engine"); return LDX_EINVAL; }
     if (e->impl->finalized) { set_error("ldx_flux_set_fp8: call before ldx_finalize (the weights are quantised there)"); return LDX_ESTATE; }
+    if (enable < 0 || enable > 3) { set_error("ldx_flux_set_fp8: mode must be 0 (off), 1 / 2 (linears) or 3 (linears + attention)"); return LDX_EINVAL; }
     e->impl->fx_fp8 = enable != 0;
-    e->impl->fx_fp8_attn = enable == 1;        // 1: linears AND attention; 2: linears only (the round-2 .. 4 behaviour: QK^T / PV stay 16-bit)
+    e->impl->fx_fp8_attn = enable == 3;        // 1 (= 2): the linears only, QK^T / PV stay 16-bit — what the mode has meant since round 2; 3: linears AND attention (explicit opt-in)
     return LDX_OK;
     GUARD_END
 }
@@ -260,6 +261,27 @@ int ldx_unet_denoise_cfg(ldx_engine* e, const float* x, float sigma, const float
     return e->impl->run_cfg(x, sigma, ctx, B, h, w, M, out, (hipStream_t)stream);
     GUARD_END
 }
+int ldx_unet_denoise_cfg_t(ldx_engine* e, const float* x, float sigma, int t_index, const float* ctx, int B, int h, int w, int M, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise_cfg_t: not a UNet engine"); return LDX_ESTATE; }
+    return e->impl->run_cfg(x, sigma, ctx, B, h, w, M, out, (hipStream_t)stream, t_index < 0 ? -1 : t_index);
+    GUARD_END
+}
+int ldx_unet_denoise_t(ldx_engine* e, const float* x, const float* sigma, const float* t_index, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_denoise_t: not a UNet engine"); return LDX_ESTATE; }
+    if (!t_index) { set_error("ldx_unet_denoise_t: t_index is null (use ldx_unet_denoise)"); return LDX_EINVAL; }
+    return e->impl->run(x, sigma, ctx, B2, h, w, M, out, true, (hipStream_t)stream, 0, nullptr, 0, t_index);
+    GUARD_END
+}
+int ldx_unet_timestep(ldx_engine* e, const float* sigma, int n, int32_t* t_out, void* stream) {
+    GUARD_BEGIN
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    return e->impl->timestep_lookup(sigma, n, (int*)t_out, (hipStream_t)stream);
+    GUARD_END
+}
 int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float* ctx, int B2, int h, int w, int M, float* out, void* stream) {
     GUARD_BEGIN
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
@@ -270,8 +292,20 @@ int ldx_unet_forward(ldx_engine* e, const float* x, const float* t, const float*
 int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* arena_bytes) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     if (n_launches) *n_launches = e->impl->n_launches();
-    if (flops) *flops = e->impl->steady_flops();
+    if (flops) *flops = e->impl->algorithmic_flops();
     if (arena_bytes) *arena_bytes = (int64_t)e->impl->arena_cap;
+    return LDX_OK;
+}
+int ldx_plan_flops(ldx_engine* e, double* executed, double* shared) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (executed) *executed = e->impl->steady_flops();
+    if (shared) *shared = e->impl->flops_shared;
+    return LDX_OK;
+}
+int ldx_unet_cfg_share(ldx_engine* e, int enable) {
+    if (!e) { set_error("null engine"); return LDX_EINVAL; }
+    if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_cfg_share: not a UNet engine"); return LDX_ESTATE; }
+    e->impl->cfg_share = enable != 0;
     return LDX_OK;
 }
 int ldx_profile(ldx_engine* e, int enable, int reset) {

@@ -106,6 +106,7 @@ static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(const ldx_unet_config& c, int dev) : cfg(c), device(dev) {
     dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
+    cfg_share = !(getenv("LDX_CFG_SHARE") && atoi(getenv("LDX_CFG_SHARE")) == 0);
 }
 Engine::~Engine() {
     (void)hipSetDevice(device);
@@ -150,6 +151,8 @@ int Engine::load_tensor(const char* key, const void* data, int dtype, const int6
 }
 
 int Engine::set_tables(const float* ls, int n, const float* temb, int dim) {
+    // after finalize the per-timestep emb_layers table (build_emb_table) and every cached plan depend on these tables
+    if (finalized) { set_error("ldx_set_tables after ldx_finalize"); return LDX_ESTATE; }
     if (!ls || !temb || n <= 0 || dim != cfg.model_channels) { set_error("ldx_set_tables: bad argument (temb_dim must equal model_channels)"); return LDX_EINVAL; }
     HIP_OK(hipSetDevice(device));
     void* p = nullptr;
@@ -683,11 +686,22 @@ void Engine::op_attn(const char* name, const void* Q, int ldq, const void* K, in
     {
         const int ks = D <= 32 ? 1 : D <= 64 ? 2 : D <= 96 ? 3 : D <= 128 ? 4 : 5;
         const int dtl = D / 16 + 1;
+        const int cls = attention_dispatch_class(a);         // the device kernel's own name where one family takes the launch (rocprofv3 reports the same)
         if (attn512_ok(a)) snprintf(o.klabel, sizeof(o.klabel), "attn512_kernel<%s>x%d", dt == DT_BF16 ? "bf16" : "f16", a.nsplit);
+        else if (cls == 1 || cls == 2) snprintf(o.klabel, sizeof(o.klabel), "%s<%s>%s", cls == 1 ? "attn40p_kernel" : "attn128p_kernel", dt == DT_BF16 ? "bf16" : "f16", Nq == Mk ? "self" : "cross");
         else snprintf(o.klabel, sizeof(o.klabel), "attn_kernel<%s,%d,%d>%s", dt == DT_BF16 ? "bf16" : "f16", ks, dtl, Nq == Mk ? "self" : "cross");
     }
     ops.push_back(o);
     flops += o.flops;
+}
+
+// rows [0, rows) of the view -> rows [rows, 2 * rows): the second half of a CFG batch takes over what was computed once for both (plan(): share)
+void Engine::op_dup(const Act& a, int rows) {
+    Op o{}; o.kind = OP_DUP; o.name = "cfg.dup";
+    o.p0 = ptr(a); o.p1 = arena ? (char*)ptr(a) + (size_t)rows * a.ld * 2 : nullptr; o.i0 = rows; o.i1 = a.C; o.i2 = a.ld;
+    o.bytes = 2.0 * 2.0 * (double)rows * a.C;
+    snprintf(o.klabel, sizeof(o.klabel), "dup_rows");
+    ops.push_back(o);
 }
 
 Act Engine::new_act(int rows, int C) {
@@ -728,12 +742,16 @@ void Engine::emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W) {
 }
 
 // SpatialTransformer.forward (transformer.py:342-377) + BasicTransformerBlock._forward (:186-245)
-void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc) {
+void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc, int Bshare, const std::vector<DupReq>* dups) {
     const int M = B * H * W, C = x.C, heads = cfg.num_heads, D = C / heads;
+    // Shared CFG prefix (plan(): share): up to the first cross-attention both halves of the batch hold the same values, so norm / proj_in / norm1 / q|k|v /
+    // self-attention / to_out of the FIRST transformer block run on the first Bq samples (rows [0, Mq)) only
+    int Bq = Bshare > 0 ? Bshare : B, Mq = Bq * H * W;
+    auto head = [&](const Act& a) { Act v = a; v.rows = Mq; v.owned = false; return v; };      // the first Mq rows of a buffer
     Act t1 = new_act(M, C);
-    op_gn("xf.norm", X, t1, B, H * W, x.gn, 1e-6f, false);
+    op_gn("xf.norm", X, t1, Bq, H * W, x.gn, 1e-6f, false);
     Act h = new_act(M, C);
-    op_gemm("xf.proj_in", t1, x.proj_in, h, Act{});
+    op_gemm("xf.proj_in", head(t1), x.proj_in, head(h), Act{});
     release(t1);
     // Folded LayerNorms (XfBlockW::ln_fold): the q|k|v / q / GEGLU GEMM reads h itself, accumulates each row's statistics from its own A
     // fragments and normalises in its epilogue (GemmArgs::ln_c1): no LayerNorm launch, no normalised copy of h.  A split-K consumer keeps a
@@ -748,8 +766,8 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     const bool fold = x.depth > 0 && x.blocks[0].ln_fold && !rowblocks && (long)M * C <= fold_maxrows * 320;      // 8192 rows at C = 320, 2048 at C = 1280
     Act n{};
     auto ln_gemm = [&](const char* ln_name, const char* name, const NormW& ln, const LinearW& w, const float* c1, Act Cc, bool geglu) {
-        if (fold && gemm_choose_splitk(M, w.N, w.K, geglu) == 1) {
-            op_gemm(name, h, w, Cc, Act{}, geglu);
+        if (fold && gemm_choose_splitk(Mq, w.N, w.K, geglu) == 1) {
+            op_gemm(name, head(h), w, head(Cc), Act{}, geglu);
             GemmArgs& g = ops.back().g;
             g.ln_c1 = c1; g.ln_eps = 1e-5f;
             return;
@@ -757,21 +775,27 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
         if (!n.valid) n = new_act(M, C);
         NormW plain = ln;
         if (fold) { plain.g = nullptr; plain.b = nullptr; }     // gamma / beta already live in the folded weights / bias
-        op_ln(ln_name, h, n, plain);
-        op_gemm(name, n, w, Cc, Act{}, geglu);
+        op_ln(ln_name, head(h), head(n), plain);
+        op_gemm(name, head(n), w, head(Cc), Act{}, geglu);
     };
     for (int d = 0; d < x.depth; ++d) {
         const XfBlockW& b = x.blocks[d];
         Act qkv = new_act(M, 3 * C);
-        if (fold || b.qkv.b || !op_rowgemm("xf.ln1+qkv", h, b.qkv, qkv, Act{}, 1, &b.ln1))        // LayerNorm + q|k|v projection as one launch (C = 320)
+        if (fold || b.qkv.b || !op_rowgemm("xf.ln1+qkv", head(h), b.qkv, head(qkv), Act{}, 1, &b.ln1))        // LayerNorm + q|k|v projection as one launch (C = 320)
             ln_gemm("xf.ln1", "xf.qkv", b.ln1, fold ? b.qkv_f : b.qkv, b.c1_qkv, qkv, false);
         Act a = new_act(M, C);
         const char* base = (const char*)ptr(qkv);
-        op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, B, heads, H * W, H * W, D);
+        op_attn("xf.attn1", base, 3 * C, base + (size_t)C * 2, 3 * C, base + (size_t)2 * C * 2, 3 * C, a, Bq, heads, H * W, H * W, D);
         if (q_prescale()) ops.back().at.scale = 1.0f / 1.44269504088896340736f;       // the q rows of the projection already carry scale * log2(e)
         release(qkv);
-        if (!op_rowgemm("xf.o1", a, b.o1, h, h, 0, nullptr))
-            op_gemm("xf.o1", a, b.o1, h, h);                   // x += attn1(norm1(x))   (in place)
+        if (!op_rowgemm("xf.o1", head(a), b.o1, head(h), head(h), 0, nullptr))
+            op_gemm("xf.o1", head(a), b.o1, head(h), head(h));                   // x += attn1(norm1(x))   (in place)
+        if (Bq != B) {
+            // the context enters here: from now on the halves differ.  The second half's rows take over the shared results that full-batch ops still read.
+            if (dups) for (const DupReq& dq : *dups) op_dup(dq.a, dq.rows);
+            op_dup(h, Mq);
+            Bq = B; Mq = M;
+        }
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
         XAttnArgs xa{};
@@ -824,7 +848,13 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     release(h);
 }
 
-int Engine::plan(int B2, int h, int w, int Mc) {
+int Engine::plan(int B2, int h, int w, int Mc, int share) {
+    // share: only meaningful when some block has a cross-attention for the prefix to end at, and B2 = 2 * share
+    if (share > 0) {
+        bool any_xf = false;
+        for (auto& blk : in_blocks) any_xf = any_xf || blk.has_xf;
+        if (!any_xf || B2 != 2 * share) share = 0;
+    }
     // dry run (arena == nullptr) measures the peak; second run binds real pointers
     for (int pass = 0; pass < 2; ++pass) {
         ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
@@ -883,22 +913,35 @@ int Engine::plan(int B2, int h, int w, int Mc) {
 
         int lv = 0, s = 0;
         Act hcur = skip_view(0);
-        op_conv("conv_in", xin, B2, h, w, 64, conv_in, 1, h, w, hcur, Act{});
-        flops -= 2.0 * B2 * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);   // padded channels are not algorithmic work
+        // Bp: batch of the ops in front of the first cross-attention (share > 0: one half of the CFG batch stands for both); `pend` = what they produce
+        // that later full-batch ops read (the skip connections), duplicated into the second half's rows when the prefix ends (emit_xf)
+        int Bp = share > 0 ? share : B2;
+        std::vector<DupReq> pend;
+        op_conv("conv_in", xin, Bp, h, w, 64, conv_in, 1, h, w, hcur, Act{});
+        flops -= 2.0 * Bp * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);   // padded channels are not algorithmic work
         release(xin);
+        if (Bp != B2) pend.push_back({hcur, Bp * h * w});
         for (auto& blk : in_blocks) {
             ++s;
             Act dst = skip_view(s);
             if (blk.has_down) {
-                op_conv("down", hcur, B2, Hs[lv], Ws[lv], in_ch[s - 1], blk.down, 2, Hs[lv + 1], Ws[lv + 1], dst, Act{});
+                op_conv("down", hcur, Bp, Hs[lv], Ws[lv], in_ch[s - 1], blk.down, 2, Hs[lv + 1], Ws[lv + 1], dst, Act{});
                 ++lv;
+                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv]});
             } else if (blk.has_xf) {
                 Act mid = new_act(B2 * Hs[lv] * Ws[lv], blk.res.Cout);
-                emit_res(blk.res, hcur, mid, B2, Hs[lv], Ws[lv]);
-                emit_xf(blk.xf, mid, dst, B2, Hs[lv], Ws[lv], ctx16, Mc);
+                emit_res(blk.res, hcur, mid, Bp, Hs[lv], Ws[lv]);
+                if (Bp != B2) {
+                    pend.push_back({mid, Bp * Hs[lv] * Ws[lv]});          // proj_out's residual reads it for every sample
+                    emit_xf(blk.xf, mid, dst, B2, Hs[lv], Ws[lv], ctx16, Mc, Bp, &pend);
+                    Bp = B2; pend.clear();
+                } else {
+                    emit_xf(blk.xf, mid, dst, B2, Hs[lv], Ws[lv], ctx16, Mc);
+                }
                 release(mid);
             } else {
-                emit_res(blk.res, hcur, dst, B2, Hs[lv], Ws[lv]);
+                emit_res(blk.res, hcur, dst, Bp, Hs[lv], Ws[lv]);
+                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv]});
             }
             hcur = dst;
         }
@@ -966,11 +1009,17 @@ int Engine::plan(int B2, int h, int w, int Mc) {
         }
         { Op o{}; o.kind = OP_FINISH; o.name = "finish"; ops.push_back(o); }
         release(ctx16); release(kvall);
+        // what the shared prefix saves: every op in front of the first hand-over copy ran on half the batch (the context-only ops are not part of it)
+        flops_shared = 0;
+        if (share > 0) {
+            for (const Op& o : ops) { if (o.kind == OP_DUP) break; if (!o.ctx_only) flops_shared += o.flops; }
+            flops_shared -= 2.0 * share * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);        // conv_in's padded channels are not algorithmic work (see above)
+        }
         fuse_gn_stats();
         fuse_gn_rowgemm();
         if (!bind) { arena_peak_dry = arena_peak; arena = saved_arena; }
     }
-    pB2 = B2; ph = h; pw = w; pM = Mc;
+    pB2 = B2; ph = h; pw = w; pM = Mc; pShare = share;
     graph_valid = false; warm = false;
     kv_ptr = nullptr; kv_epoch = 0;          // a fresh arena holds no projected context
     return LDX_OK;
@@ -983,14 +1032,22 @@ int Engine::build_emb_table() {
     if (off || d_emb_table || !d_temb || n_sigmas <= 0 || emb_total <= 0 || emb_total % 4) return LDX_OK;
     const int mc = cfg.model_channels, ted = 4 * mc, n = n_sigmas;
     float *e1 = nullptr, *e2 = nullptr, *tab = nullptr;
-    HIP_OK(hipMalloc((void**)&e1, (size_t)n * ted * 4));
-    HIP_OK(hipMalloc((void**)&e2, (size_t)n * ted * 4));
-    HIP_OK(hipMalloc((void**)&tab, (size_t)n * emb_total * 4));
+    auto fail = [&](hipError_t err, const char* what) {       // nothing of a half-built table survives an error
+        if (e1) (void)hipFree(e1);
+        if (e2) (void)hipFree(e2);
+        if (tab) (void)hipFree(tab);
+        set_error(std::string(what) + ": " + hipGetErrorString(err));
+        return LDX_EHIP;
+    };
+    hipError_t err;
+    if ((err = hipMalloc((void**)&e1, (size_t)n * ted * 4)) != hipSuccess) return fail(err, "build_emb_table: hipMalloc");
+    if ((err = hipMalloc((void**)&e2, (size_t)n * ted * 4)) != hipSuccess) return fail(err, "build_emb_table: hipMalloc");
+    if ((err = hipMalloc((void**)&tab, (size_t)n * emb_total * 4)) != hipSuccess) return fail(err, "build_emb_table: hipMalloc");
     launch_skinny(SkinnyArgs{d_temb, mc, te0.w, te0.b, e1, ted, n, ted, mc, 0, 1}, dt, nullptr);
     launch_skinny(SkinnyArgs{e1, ted, te2.w, te2.b, e2, ted, n, ted, ted, 0, 1}, dt, nullptr);
     launch_skinny(SkinnyArgs{e2, ted, emb_all.w, emb_all.b, tab, emb_total, n, emb_total, ted, 0, 0}, dt, nullptr);
-    HIP_OK(hipStreamSynchronize(nullptr));
-    HIP_OK(hipGetLastError());
+    if ((err = hipStreamSynchronize(nullptr)) != hipSuccess) return fail(err, "build_emb_table: hipStreamSynchronize");
+    if ((err = hipGetLastError()) != hipSuccess) return fail(err, "build_emb_table: kernel launch");
     (void)hipFree(e1); (void)hipFree(e2);
     dev_allocs.push_back(tab);
     d_emb_table = tab;
@@ -1003,18 +1060,20 @@ double Engine::steady_flops() const {
     if (ctx_cache) for (const Op& o : ops) if (o.ctx_only) f -= o.flops;
     return f;
 }
+// the reference's arithmetic for the same evaluation: what runs plus what the shared CFG prefix computes once instead of twice
+double Engine::algorithmic_flops() const { return steady_flops() + flops_shared; }
 
 void Engine::plan_stash() {
     PlanSnap s;
-    s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.ops = std::move(ops); s.flops = flops; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
+    s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.share = pShare; s.ops = std::move(ops); s.flops = flops; s.flops_shared = flops_shared; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
     s.kv_ptr = kv_ptr; s.kv_epoch = kv_epoch; s.g_ctxc = g_ctxc;
-    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB; s.g_cc = g_cc; s.g_ccn = g_ccn;
+    s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB; s.g_cc = g_cc; s.g_ccn = g_ccn; s.g_t = g_t;
     s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
     s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
     s.fb_B = fb_B; s.fb_L = fb_L; s.fb_Lt = fb_Lt; s.fb_C = fb_C; s.fb_a_end = fb_a_end; s.fb_b_end = fb_b_end;
-    ops.clear(); arena = nullptr; arena_cap = 0; graph_exec = nullptr; graph_valid = false; warm = false; pB2 = ph = pw = pM = 0;
+    ops.clear(); arena = nullptr; arena_cap = 0; graph_exec = nullptr; graph_valid = false; warm = false; pB2 = ph = pw = pM = 0; pShare = 0;
     plan_cache.push_back(std::move(s));
     // every cached plan keeps its own arena resident: bound the cache by count (4) AND by bytes (LDX_PLAN_CACHE_GIB, default 16 GiB of
     // stashed arenas — a Flux plan per prompt length, a 2048^2 VAE plan of several GiB ...); oldest first, the newest entry always stays
@@ -1027,19 +1086,19 @@ void Engine::plan_stash() {
         plan_cache.erase(plan_cache.begin());
     }
 }
-bool Engine::plan_restore(int B2, int h, int w, int Mc) {
+bool Engine::plan_restore(int B2, int h, int w, int Mc, int share) {
     for (size_t i = 0; i < plan_cache.size(); ++i) {
         PlanSnap& s = plan_cache[i];
-        if (s.B2 != B2 || s.h != h || s.w != w || s.M != Mc) continue;
-        ops = std::move(s.ops); flops = s.flops; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
+        if (s.B2 != B2 || s.h != h || s.w != w || s.M != Mc || s.share != share) continue;
+        ops = std::move(s.ops); flops = s.flops; flops_shared = s.flops_shared; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
         kv_ptr = s.kv_ptr; kv_epoch = s.kv_epoch; g_ctxc = s.g_ctxc;
-        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB; g_cc = s.g_cc; g_ccn = s.g_ccn;
+        graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB; g_cc = s.g_cc; g_ccn = s.g_ccn; g_t = s.g_t;
         fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
         fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
         fb_B = s.fb_B; fb_L = s.fb_L; fb_Lt = s.fb_Lt; fb_C = s.fb_C; fb_a_end = s.fb_a_end; fb_b_end = s.fb_b_end;
-        pB2 = B2; ph = h; pw = w; pM = Mc;
+        pB2 = B2; ph = h; pw = w; pM = Mc; pShare = share;
         plan_cache.erase(plan_cache.begin() + i);
         return true;
     }
@@ -1064,7 +1123,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
                 p.x = b_x; p.sigma = b_s; p.B = pB2; p.C = cfg.in_channels; p.H = ph; p.W = pw; p.Cpad = 64;
                 p.xc = (char*)arena + prep_xc_off; p.log_sigmas = d_log_sigmas; p.n_sigmas = n_sigmas;
                 p.temb_table = d_temb; p.temb_dim = cfg.model_channels; p.temb_out = d_temb_out; p.t_out = nullptr;
-                p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? nullptr : b_s; p.xB = b_xB;
+                p.scale_input = b_den ? 1 : 0; p.t_in = b_den ? b_t : b_s; p.xB = b_xB;      // b_t: indices from the caller (null: looked up from sigma on the device)
                 p.cc = b_cc; p.Cx = cfg.in_channels - b_ccn;
                 if (kind == KIND_UNET && d_emb_table) { p.emb_table = d_emb_table; p.emb_n = emb_total; p.emb_out = d_emb_all; }
                 launch_prep(p, dt, ls);
@@ -1117,6 +1176,7 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
             case OP_PIXPREP: launch_pixels_prep(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, o.f0, o.f1, dt, ls); break;
             case OP_COPY_OUT: HIP_OK(hipMemcpyAsync(b_out, o.p0, (size_t)o.cvt_n, hipMemcpyDeviceToDevice, ls)); break;
             case OP_MOMENTS: launch_mix_nhwc_to_nchw((const float*)o.p0, o.i1, b_out, o.i0, o.i1, o.i2, enc_qc, enc_qc ? enc_qc + o.i1 * o.i1 : nullptr, ls); break;
+            case OP_DUP: launch_dup_rows(o.p0, o.p1, o.i0, o.i1, o.i2, dt, ls); break;
             case OP_FX_TEMB: launch_flux_temb(o.i0 ? b_guid : b_s, (float*)o.p1, pB2, 256, 1000.0f, ls); break;
             case OP_FX_SILU: launch_silu_f32((const float*)o.p0, (float*)o.p1, (size_t)o.i0, ls); break;
             case OP_FX_PATCH: launch_flux_patchify(b_x, o.p1, o.i0, o.i1, o.i2, o.i3, dt, ls); break;
@@ -1155,22 +1215,34 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
     return LDX_OK;
 }
 
-int Engine::run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st) {
+int Engine::run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st, int t_index) {
     if (B <= 0) { set_error("ldx_unet_denoise_cfg: bad argument"); return LDX_EINVAL; }
+    if (t_index >= n_sigmas) { set_error("ldx_unet_denoise_cfg_t: t_index outside the sigma table"); return LDX_EINVAL; }
     HIP_OK(hipSetDevice(device));
     if (sigma_cfg_cap < 2 * B) {
         HIP_OK(hipStreamSynchronize(st));
         if (d_sigma_cfg) (void)hipFree(d_sigma_cfg);
         d_sigma_cfg = nullptr; sigma_cfg_cap = 0;
-        HIP_OK(hipMalloc((void**)&d_sigma_cfg, sizeof(float) * 2 * B));
+        HIP_OK(hipMalloc((void**)&d_sigma_cfg, sizeof(float) * 4 * B));
         sigma_cfg_cap = 2 * B;
     }
     launch_fill_f32(d_sigma_cfg, sigma, 2 * B, st);          // outside the captured graph: the value changes every step
-    return run(x, d_sigma_cfg, ctx, 2 * B, h, w, Mc, out, true, st, B);
+    float* d_t = d_sigma_cfg + sigma_cfg_cap;
+    if (t_index >= 0) launch_fill_f32(d_t, (float)t_index, 2 * B, st);
+    return run(x, d_sigma_cfg, ctx, 2 * B, h, w, Mc, out, true, st, B, nullptr, 0, t_index >= 0 ? d_t : nullptr);
+}
+int Engine::timestep_lookup(const float* sigma_dev, int n, int* out_dev, hipStream_t st) {
+    if (kind != KIND_UNET || !d_log_sigmas) { set_error("ldx_unet_timestep: needs a UNet engine with its sigma table (ldx_set_tables)"); return LDX_ESTATE; }
+    if (!sigma_dev || !out_dev || n < 0) { set_error("ldx_unet_timestep: bad argument"); return LDX_EINVAL; }
+    HIP_OK(hipSetDevice(device));
+    launch_timestep(sigma_dev, d_log_sigmas, n_sigmas, n, out_dev, st);
+    HIP_OK(hipGetLastError());
+    return LDX_OK;
 }
 
 int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB,
-                const float* c_concat, int cc_channels) {
+                const float* c_concat, int cc_channels, const float* t_idx) {
+    if (!denoise) t_idx = nullptr;            // forward mode: sigma_or_t already carries the indices
     if (c_concat && (cc_channels <= 0 || cc_channels >= cfg.in_channels || (denoise && cfg.in_channels - cc_channels != cfg.out_channels))) {
         set_error("ldx_unet_denoise_concat: c_concat channels must leave the latent's channels (in_channels - cc_channels == out_channels)"); return LDX_EINVAL;
     }
@@ -1179,11 +1251,14 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     if (!finalized) { set_error("ldx_unet_*: engine not finalized"); return LDX_ESTATE; }
     if (!x || !sigma_or_t || !ctx || !out || B2 <= 0 || h <= 0 || w <= 0 || Mc <= 0) { set_error("ldx_unet_*: bad argument"); return LDX_EINVAL; }
     HIP_OK(hipSetDevice(device));
-    if (B2 != pB2 || h != ph || w != pw || Mc != pM) {
+    // CFG evaluation over one latent batch (ldx_unet_denoise_cfg*: xB > 0 and B2 == 2 xB): the two halves are identical up to the first cross-attention, which
+    // the plan then computes once (plan(): share).  LDX_CFG_SHARE=0: every op on the full batch, as the concatenated ldx_unet_denoise call runs it.
+    const int share = (cfg_share && denoise && xB > 0 && B2 == 2 * xB && !c_concat) ? xB : 0;
+    if (B2 != pB2 || h != ph || w != pw || Mc != pM || share != pShare) {
         HIP_OK(hipStreamSynchronize(st));
         if (pB2 > 0) plan_stash();
-        if (!plan_restore(B2, h, w, Mc)) {
-            int rc = plan(B2, h, w, Mc);
+        if (!plan_restore(B2, h, w, Mc, share)) {
+            int rc = plan(B2, h, w, Mc, share);
             if (rc) return rc;
         }
     }
@@ -1191,14 +1266,14 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     // other op (and the captured graph) then leaves them out
     const bool ctxc = ctx_cache;
     b_ctx = ctx;
-    if (ctxc && !(kv_ptr == ctx && kv_epoch == ctx_epoch)) {
+    if (ctxc && !(kv_ptr == ctx && kv_epoch == ctx_epoch && kv_stream == st)) {
         const bool pg = prof_graph; prof_graph = false;
         const int rc = exec_ops(st, 0, (size_t)-1, 2);
         prof_graph = pg;
         if (rc) return rc;
-        kv_ptr = ctx; kv_epoch = ctx_epoch;
+        kv_ptr = ctx; kv_epoch = ctx_epoch; kv_stream = st;
     }
-    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB && g_cc == c_concat && g_ccn == cc_channels && g_ctxc == ctxc);
+    const bool same = (g_x == x && g_s == sigma_or_t && g_ctx == ctx && g_out == out && g_den == denoise && g_xB == xB && g_cc == c_concat && g_ccn == cc_channels && g_ctxc == ctxc && g_t == t_idx);
     // a captured graph has its pointers baked in: once a call arrives with other bindings (in ANY mode — the eager path below re-records
     // g_*), that graph must never be replayed against the new g_* (round 3: a stale graph was replayed after an eager call had moved g_*)
     if (!same) graph_valid = false;
@@ -1210,7 +1285,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     // capture only once the same (plan, pointers) have been run eagerly before: the first eager pass
     // also performs the one-time hipFuncSetAttribute calls, which are illegal during capture.
     const bool use_graph = graph_mode && warm && same;
-    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; g_cc = c_concat; g_ccn = cc_channels; g_ctxc = ctxc; warm = true;
+    g_x = x; g_s = sigma_or_t; g_ctx = ctx; g_out = out; g_den = denoise; g_xB = xB; g_cc = c_concat; g_ccn = cc_channels; g_ctxc = ctxc; g_t = t_idx; warm = true;
     hipStream_t ls = st;
     if (use_graph) {
         if (graph_exec) { (void)hipGraphExecDestroy(graph_exec); graph_exec = nullptr; }
@@ -1219,7 +1294,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
         HIP_OK(hipStreamBeginCapture(cap_stream, hipStreamCaptureModeThreadLocal));
         ls = cap_stream;
     }
-    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB; b_cc = c_concat; b_ccn = cc_channels;
+    b_x = x; b_s = sigma_or_t; b_ctx = ctx; b_out = out; b_den = denoise; b_xB = xB; b_cc = c_concat; b_ccn = cc_channels; b_t = t_idx;
     prof_graph = use_graph;
     { int rc = exec_ops(ls, 0, (size_t)-1, ctxc ? 1 : 0); if (rc) return rc; }
     if (use_graph) {

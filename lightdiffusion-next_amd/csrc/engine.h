@@ -43,14 +43,13 @@ struct Act { bool valid = false; bool owned = false; size_t off = 0; int rows = 
 enum OpKind { OP_PREP, OP_CVT, OP_SKINNY, OP_GEMM, OP_GN, OP_LN, OP_ATTN, OP_FINISH,
               OP_VAEPREP, OP_SOFTMAX, OP_CLAMP, OP_EMBED, OP_CVT_OUT,
               OP_PIXPREP, OP_MOMENTS, OP_COPY_OUT,
-              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK, OP_ROWGEMM, OP_ATTN_MX, OP_MXVT };
+              OP_FX_PATCH, OP_FX_TEMB, OP_FX_SILU, OP_FX_ROPE, OP_FX_UNPATCH, OP_FX_CVT_CTX, OP_FX_SKINNY_Y, OP_FX_SKINNY_G, OP_MXQ, OP_GEMM2, OP_XATTN, OP_FFBLOCK, OP_ROWGEMM, OP_ATTN_MX, OP_MXVT, OP_DUP };
 enum EngineKind { KIND_UNET = 0, KIND_VAE = 1, KIND_CLIP = 2, KIND_FLUX = 3, KIND_T5 = 4, KIND_ESRGAN = 5 };
 struct Op {
     OpKind kind; const char* name;
     GemmArgs g; GemmArgs g2; GroupNormArgs gn; LayerNormArgs ln; AttnArgs at; SkinnyArgs sk; QkRopeArgs rp; MxQuantArgs mq; XAttnArgs xa; FFBlockArgs fb; RowGemmArgs rg; AttnMxArgs am; MxVtArgs vt;
     void* cvt_out; size_t cvt_n;
     bool ctx_only = false;         // depends on the context alone (16-bit copy of ctx, the batched k|v projection): skipped while Engine::ctx_cache holds
-    bool emb_path = false;         // the time-embedding MLP / emb_layers launches: skipped when the per-timestep table exists (Engine::d_emb_table)
     // generic slots for the small ops: src/dst pointers + dims
     const void* p0; void* p1; int i0, i1, i2, i3; float f0, f1;
     double flops; double bytes; char klabel[48];
@@ -119,12 +118,15 @@ public:
     int set_tables(const float* ls, int n, const float* temb, int dim);
     int finalize();
     // c_concat [B2][cc_channels][h][w] (fp32, may be null): appended unscaled behind the scaled x, which then carries in_channels - cc_channels channels
+    // t_idx [B2] (device fp32, may be null; denoise only): timestep indices supplied by the caller instead of the device's own sigma -> index lookup
     int run(const float* x, const float* sigma_or_t, const float* ctx, int B2, int h, int w, int Mc, float* out, bool denoise, hipStream_t st, int xB = 0,
-            const float* c_concat = nullptr, int cc_channels = 0);
+            const float* c_concat = nullptr, int cc_channels = 0, const float* t_idx = nullptr);
     int clip_pooled(const float* last, const int* ids, int B, int T, int eos_id, float* out, hipStream_t st);
     // one CFG evaluation: x [B] is read by both halves of the [uncond; cond] batch (cond.py:186-226), sigma is one host scalar for every sample
-    int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st);
-    float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;
+    // t_index >= 0: the sigma -> timestep index computed by the caller (the reference's own host arithmetic); < 0: the device lookup
+    int run_cfg(const float* x, float sigma, const float* ctx, int B, int h, int w, int Mc, float* out, hipStream_t st, int t_index = -1);
+    int timestep_lookup(const float* sigma_dev, int n, int* out_dev, hipStream_t st);      // ldx_unet_timestep: the prep kernel's lookup alone
+    float* d_sigma_cfg = nullptr; int sigma_cfg_cap = 0;      // [2 * cap] sigma followed by [2 * cap] timestep indices
     // ---- step-invariant work (round 5) ----
     // (1) per-timestep table of the 22 emb_layers outputs: time_embed -> SiLU -> emb_layers is a pure function of the INTEGER timestep (a8: t = argmin
     //     index; unet.py:333-342, ResBlock.py:283-295), so all n_sigmas rows are computed once by the SAME skinny kernels (bit-identical to the per-step
@@ -136,12 +138,20 @@ public:
     //     them every step only because a torch module has no notion of a sampling run) are then computed on the first evaluation of a (plan, ctx) only.
     bool ctx_cache = false; uint64_t ctx_epoch = 1;
     const void* kv_ptr = nullptr; uint64_t kv_epoch = 0;       // what the CURRENT plan's kvall buffer holds
+    hipStream_t kv_stream = nullptr;                            // ... and the stream whose order it was filled in: a call on another stream refills (no cross-stream dependency is assumed)
     bool g_ctxc = false;                                        // the captured graph was recorded without the ctx_only ops
     int set_context_cache(int enable) { ctx_cache = enable != 0; ++ctx_epoch; return LDX_OK; }
+    double algorithmic_flops() const;                           // steady_flops() + flops_shared
     double steady_flops() const;                                // algorithmic flops of one forward as executed in steady state (cached ops excluded)
     unsigned* d_sk_count = nullptr;                       // split-K tile counters (sk_counters()): one zeroed buffer per engine, every launch leaves it zeroed
     unsigned* sk_counters();
-    int plan(int B2, int h, int w, int Mc);
+    // share > 0 (ldx_unet_denoise_cfg*): the evaluation batch is [uncond x share ; cond x share] over ONE latent batch x [share] — everything in front of the
+    // first cross-attention (conv_in, the ResBlocks / Downsamples / self-attention up to it) sees identical inputs in both halves and is planned on `share`
+    // samples; its results are copied into the second half's rows where the first cross-attention (and the skip connections) need them (OP_DUP).
+    int plan(int B2, int h, int w, int Mc, int share = 0);
+    int pShare = 0;
+    bool cfg_share = true;                 // ldx_unet_cfg_share / LDX_CFG_SHARE: plan CFG evaluations with the shared prefix
+    double flops_shared = 0;               // flops the current plan does NOT execute because of it (the second half's copy of the prefix ops)
     int64_t n_launches() const;
     int64_t n_graph_captures = 0, n_graph_replays = 0;      // ldx_graph_stats (tests: the sampler loops must replay, not re-capture)
     // per-kernel-class HIP-event profile of subsequent forwards (bench.py roofline leg)
@@ -185,6 +195,7 @@ private:
     // per-call bindings read by exec_ops
     const float* b_x = nullptr; const float* b_s = nullptr; const float* b_ctx = nullptr; float* b_out = nullptr; bool b_den = false; int b_xB = 0, g_xB = 0;
     const float* b_cc = nullptr; const float* g_cc = nullptr; int b_ccn = 0, g_ccn = 0;
+    const float* b_t = nullptr; const float* g_t = nullptr;       // caller-supplied timestep indices (run(): t_idx)
     const int* b_ids = nullptr; float* b_out2 = nullptr;
     // VAE
     std::vector<std::vector<ResW>> vae_up; std::vector<LinearW> vae_upconv; std::vector<bool> vae_has_up;
@@ -242,17 +253,21 @@ private:
     void emit_res(const ResW& r, Act X, Act OUT, int B, int H, int W);
     void emit_vae_attn(const VaeAttnW& a, Act X, Act OUT, int B, int H, int W);
     bool mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r);
-    void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc);
+    // Bshare > 0: the ops in front of the first cross-attention run on Bshare samples (see plan()); `dups` = views whose first Bshare * (their own H * W)
+    // rows are to be copied into the following rows at that point (plus h itself)
+    struct DupReq { Act a; int rows; };
+    void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc, int Bshare = 0, const std::vector<DupReq>* dups = nullptr);
+    void op_dup(const Act& a, int rows);          // rows [0, rows) of view a -> rows [rows, 2 rows)
 
     // UNet plans of other input shapes seen (multi-scale samplers alternate between two resolutions): launch plan, arena and
     // captured graph are kept per shape, so switching back costs nothing (a re-plan + two eager passes before the graph is
     // usable again cost ~17 ms per switch)
     struct PlanSnap {
-        int B2 = 0, h = 0, w = 0, M = 0; std::vector<Op> ops; double flops = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
+        int B2 = 0, h = 0, w = 0, M = 0, share = 0; std::vector<Op> ops; double flops = 0, flops_shared = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
         const void* kv_ptr = nullptr; uint64_t kv_epoch = 0; bool g_ctxc = false;
-        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0; const float* g_cc = nullptr; int g_ccn = 0;
+        const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0; const float* g_cc = nullptr; int g_ccn = 0; const float* g_t = nullptr;
         // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
         float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;
         void *fb_s0 = nullptr, *fb_s1 = nullptr, *fb_x = nullptr; float *fb_first = nullptr, *fb_res = nullptr, *fb_part = nullptr;
@@ -260,7 +275,7 @@ private:
     };
     std::vector<PlanSnap> plan_cache;
     void plan_stash();                    // move the current plan into plan_cache (evicting the oldest beyond 4)
-    bool plan_restore(int B2, int h, int w, int Mc);
+    bool plan_restore(int B2, int h, int w, int Mc, int share = 0);
     std::vector<hipEvent_t> prof_events;
     bool prof_graph = false;
     // graph replay

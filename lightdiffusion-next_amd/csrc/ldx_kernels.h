@@ -141,6 +141,7 @@ struct AttnArgs {
     float* split_ws; int nsplit;
 };
 void launch_attention(const AttnArgs& a, DType dt, hipStream_t s);
+int attention_dispatch_class(const AttnArgs& a);       // 3 attn512_kernel, 1 attn40p_kernel, 2 attn128p_kernel, 0 generic (attn32g / attn32 / attn)
 // launch_attention's dispatch switches (LDX_ATTN_PIPE, LDX_ATTN_PIPE128, LDX_ATTN_PIPE_MINWG, LDX_ATTN_PIPE_THR) are read once at load;
 // this re-reads them (tests / same-process A/B runs only — never on the launch path)
 void reload_dispatch_env();
@@ -252,9 +253,13 @@ struct PrepArgs {
     const float* emb_table; int emb_n; float* emb_out;
 };
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s);
+// out[i] = nearest log-sigma table index of sigma[i] (the prep kernel's own lookup; ldx_unet_timestep)
+void launch_timestep(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int* out, hipStream_t s);
 // finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)
 struct FinishArgs { const float* eps; int ld; const float* x; const float* sigma; float* out; int B, C, HW; int xB; };       // xB as in PrepArgs
 void launch_fill_f32(float* dst, float v, int n, hipStream_t s);
+// dst[r][0:C) = src[r][0:C) for r in [0, rows): 16-bit elements, both with row stride ld, C % 8 == 0 (the shared CFG prefix's hand-over, Engine::op_dup)
+void launch_dup_rows(const void* src, void* dst, int rows, int C, int ld, DType dt, hipStream_t s);
 // CLIP pooled output: row of last[b] at the first position whose id == eos_id (position 0 if none: torch argmax of an all-zero row),
 // then, if proj != null, out[b] = row @ proj^T (proj [E][E] fp32, row-major [out][in])
 void launch_clip_pooled(const float* last, const int* ids, int B, int T, int E, int eos_id, const float* proj, float* out, hipStream_t s);

@@ -36,35 +36,39 @@ __global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p) {
     }
 }
 
-// one block per sample: nearest log-sigma table index (first minimum, like torch.argmin), then
-// copy the host-built sinusoidal embedding row.
+// ModelSamplingDiscrete.timestep (sample/sampling.py:309-320): index of the log-sigma table entry nearest to log(sigma), first minimum like
+// torch.argmin.  One workgroup of 256 threads; sd / si are its scratch; every thread returns the index.
+static __device__ __forceinline__ int nearest_log_sigma(const float sigma, const float* __restrict__ log_sigmas, const int n, float* sd, int* si) {
+    const int tid = threadIdx.x;
+    // log in fp64, rounded once: the correctly rounded fp32 logarithm.  The reference's torch CPU log is correctly rounded for 99.98 % of inputs (894 of 4 M
+    // sampled differ), the device's logf for fewer — and at a near-tie (sigma at the geometric midpoint of two table entries) one ulp of log(sigma) decides the
+    // index: with logf the golden sigma 0.36080566 (tests/golden/schedules.npz) came out as 108 instead of 107.  Host-side sigmas do not depend on this at all
+    // (ldx_unet_denoise_cfg_t / ldx_unet_denoise_t carry the index computed by the reference's own expression).
+    const float ls = (float)log((double)sigma);
+    float best = INFINITY; int bi = 0x7fffffff;
+    for (int k = tid; k < n; k += 256) {
+        const float d = fabsf(ls - log_sigmas[k]);
+        if (d < best) { best = d; bi = k; }
+    }
+    sd[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+        if (tid < o) {
+            const float d2 = sd[tid + o]; const int i2 = si[tid + o];
+            if (d2 < sd[tid] || (d2 == sd[tid] && i2 < si[tid])) { sd[tid] = d2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    const int t = si[0];
+    __syncthreads();
+    return t;
+}
+// one block per sample: timestep index (given, or looked up from sigma), then copy the host-built sinusoidal embedding row.
 __global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
     __shared__ float sd[256];
     __shared__ int si[256];
-    __shared__ int st;
     const int b = blockIdx.x, tid = threadIdx.x;
-    if (p.t_in) {
-        if (tid == 0) st = (int)p.t_in[b];
-    } else {
-        const float ls = logf(p.sigma[b]);
-        float best = INFINITY; int bi = 0x7fffffff;
-        for (int k = tid; k < p.n_sigmas; k += 256) {
-            const float d = fabsf(ls - p.log_sigmas[k]);
-            if (d < best) { best = d; bi = k; }
-        }
-        sd[tid] = best; si[tid] = bi;
-        __syncthreads();
-        for (int o = 128; o > 0; o >>= 1) {
-            if (tid < o) {
-                const float d2 = sd[tid + o]; const int i2 = si[tid + o];
-                if (d2 < sd[tid] || (d2 == sd[tid] && i2 < si[tid])) { sd[tid] = d2; si[tid] = i2; }
-            }
-            __syncthreads();
-        }
-        if (tid == 0) st = si[0];
-    }
-    __syncthreads();
-    int t = st;
+    int t = p.t_in ? (int)p.t_in[b] : nearest_log_sigma(p.sigma[b], p.log_sigmas, p.n_sigmas, sd, si);
     t = max(0, min(t, p.n_sigmas - 1));
     // gridDim.y slices: every slice finds the same index, slice 0 writes the embedding row and the timestep, all of them share the emb_layers row copy
     // (one workgroup per sample walked its 70 KB in 17 dependent 4-KiB rounds: 14 us of a 14 ms step)
@@ -77,6 +81,16 @@ __global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
         for (int j = tid + 256 * part; j < p.emb_n / 4; j += 256 * nparts) dst[j] = src[j];
     }
     if (part == 0 && tid == 0 && p.t_out) p.t_out[b] = (float)t;
+}
+// the lookup alone (ldx_unet_timestep): the SAME device function the prep kernel runs, exposed so that the index can be tested as an integer
+__global__ __launch_bounds__(256) void timestep_kernel(const float* __restrict__ sigma, const float* __restrict__ log_sigmas, const int n_sigmas, int* __restrict__ out) {
+    __shared__ float sd[256];
+    __shared__ int si[256];
+    const int t = nearest_log_sigma(sigma[blockIdx.x], log_sigmas, n_sigmas, sd, si);
+    if (threadIdx.x == 0) out[blockIdx.x] = max(0, min(t, n_sigmas - 1));
+}
+void launch_timestep(const float* sigma, const float* log_sigmas, int n_sigmas, int n, int* out, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(timestep_kernel, dim3(n), dim3(256), 0, s, sigma, log_sigmas, n_sigmas, out);
 }
 
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s) {
@@ -126,6 +140,23 @@ void launch_clip_pooled(const float* last, const int* ids, int B, int T, int E, 
     hipLaunchKernelGGL(clip_pooled_kernel, dim3(B), dim3(256), E * sizeof(float), s, last, ids, T, E, eos_id, proj, out);
 }
 __global__ void fill_f32_kernel(float* dst, float v, int n) { const int i = blockIdx.x * 64 + threadIdx.x; if (i < n) dst[i] = v; }
+__global__ __launch_bounds__(256) void dup_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const long total, const int cpr, const int ld16) {
+    // 4 chunks in flight per thread (a copy is pure latency: 10 MB at 1024^2)
+    const long stride = (long)gridDim.x * 256;
+    for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += 4 * stride) {
+        uint4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; if (i < total) { const long r = i / cpr; v[u] = src[r * ld16 + (i - r * cpr)]; } }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) { const long i = i0 + u * stride; if (i < total) { const long r = i / cpr; dst[r * ld16 + (i - r * cpr)] = v[u]; } }
+    }
+}
+void launch_dup_rows(const void* src, void* dst, int rows, int C, int ld, DType, hipStream_t s) {
+    if (rows <= 0 || C <= 0) return;
+    const long total = (long)rows * (C / 8);
+    long grid = (total + 256 * 4 - 1) / (256 * 4); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
+    hipLaunchKernelGGL(dup_rows_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, total, C / 8, ld / 8);
+}
 void launch_fill_f32(float* dst, float v, int n, hipStream_t s) { hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, v, n); }
 void launch_finish(const FinishArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.C * a.HW;

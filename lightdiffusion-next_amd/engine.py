@@ -26,6 +26,15 @@ def sd15_sigmas():
     return sigmas.float(), sigmas.log().float()
 
 
+def timestep_index(log_sigmas: torch.Tensor, sigma) -> torch.Tensor:
+    """ModelSamplingDiscrete.timestep (src/sample/sampling.py:309-320, called from BaseModel.apply_model, ModelBase.py:112) with the reference's own torch
+    expression on the HOST: `dists = sigma.log() - log_sigmas[:, None]; dists.abs().argmin(dim=0)`.  Integer work, so it has to be bit-exact — and a device
+    logf may differ from the host's log in the last bit, which at a near-tie (sigma at the geometric midpoint of two table entries: the `normal`
+    scheduler's fractional timesteps) picks the other index.  sigma: float / host tensor; returns int64 [n]."""
+    sg = torch.as_tensor(sigma, dtype=torch.float32, device="cpu").reshape(-1)
+    return (sg.log() - log_sigmas[:, None]).abs().argmin(dim=0)
+
+
 def timestep_embedding_table(n: int, dim: int, max_period: int = 10000) -> torch.Tensor:
     """timestep_embedding (src/sample/sampling_util.py:56-76) evaluated at t = 0..n-1 -> [n][dim] fp32."""
     half = dim // 2
@@ -109,17 +118,43 @@ class UNetEngine:
         lib.check(self._lib.ldx_graph_stats(self._h, C.byref(c), C.byref(r)), "ldx_graph_stats")
         return int(c.value), int(r.value)
 
-    def _run(self, fn, x, s, ctx, out, ctx_cached=False):
+    def timestep_index(self, sigma):
+        """ModelSamplingDiscrete.timestep (sample/sampling.py:309-320) with the reference's own torch expression on the HOST: integer work, so it has to be
+        bit-exact, and a device logf may differ from the host's log in the last bit (near-ties pick the other index).  sigma: host tensor / float."""
+        return timestep_index(self.log_sigmas, sigma)
+
+    def timestep_device(self, sigma):
+        """The device's own lookup (ldx_unet_timestep): what ldx_unet_denoise runs when sigma lives on the GPU.  Returns int32 [n] on the device."""
+        sg = sigma.to(device=self.device, dtype=torch.float32).contiguous().reshape(-1)
+        out = torch.empty(sg.numel(), dtype=torch.int32, device=sg.device)
+        lib.check(self._lib.ldx_unet_timestep(self._h, lib.ptr(sg), sg.numel(), lib.ptr(out), lib.current_stream_ptr()), "ldx_unet_timestep")
+        return out
+
+    def _ctx_arg(self, ctx, device, ctx_cached):
+        """ctx as the C ABI wants it.  With the context cache on, the engine keys the cached k|v projections on the POINTER: a conversion here would hand it a
+        temporary whose address the allocator gives to the next temporary too (other contents, same key) - so a cached ctx must already be in place."""
+        if ctx_cached:
+            assert ctx.is_cuda and ctx.dtype == torch.float32 and ctx.is_contiguous(), "ctx_cached=True needs a contiguous CUDA fp32 ctx (the cache is keyed on its address)"
+            return ctx
+        return ctx.to(device=device, dtype=torch.float32).contiguous()
+
+    def _run(self, fn, x, s, ctx, out, ctx_cached=False, t_idx=None):
         self._ctx_mode(ctx_cached)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
         b2, ch, h, w = x.shape
         assert ch == self.cfg.in_channels
         x = x.contiguous()
         s = s.to(device=x.device, dtype=torch.float32).contiguous()
-        ctx = ctx.to(device=x.device, dtype=torch.float32).contiguous()
+        ctx = self._ctx_arg(ctx, x.device, ctx_cached)
         assert s.numel() == b2 and ctx.dim() == 3 and ctx.shape[0] == b2 and ctx.shape[2] == self.cfg.context_dim
         if out is None:
             out = torch.empty((b2, self.cfg.out_channels, h, w), device=x.device, dtype=torch.float32)
+        if t_idx is not None:
+            t = t_idx.to(device=x.device, dtype=torch.float32).contiguous()
+            assert t.numel() == b2
+            lib.check(self._lib.ldx_unet_denoise_t(self._h, lib.ptr(x), lib.ptr(s), lib.ptr(t), lib.ptr(ctx), b2, h, w, ctx.shape[1], lib.ptr(out),
+                                                   lib.current_stream_ptr()), "ldx_unet_denoise_t")
+            return out
         lib.check(fn(self._h, lib.ptr(x), lib.ptr(s), lib.ptr(ctx), b2, h, w, ctx.shape[1], lib.ptr(out),
                      lib.current_stream_ptr()), fn.__name__)
         return out
@@ -128,7 +163,9 @@ class UNetEngine:
         """BaseModel.apply_model (ModelBase.py:72-133): x fp32 [B2,4,h,w], sigma [B2] (values), ctx [B2,M,768].
         c_concat [B2,in_channels-4,h,w] (inpainting UNets, ModelBase.py:100-101): appended unscaled behind the scaled x inside the engine's prep kernel."""
         if c_concat is None:
-            return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out, ctx_cached)
+            # sigma on the host (the reference's CPU path, the hook's recorded calls): the timestep index comes from the reference's own torch expression
+            t_idx = self.timestep_index(sigma) if (torch.is_tensor(sigma) and not sigma.is_cuda) else None
+            return self._run(self._lib.ldx_unet_denoise, x, sigma, ctx, out, ctx_cached, t_idx=t_idx)
         self._ctx_mode(ctx_cached)
         assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4, "x must be a CUDA fp32 NCHW tensor"
         b2, ch, h, w = x.shape
@@ -136,7 +173,7 @@ class UNetEngine:
         assert cc.dim() == 4 and cc.shape[0] == b2 and cc.shape[2:] == x.shape[2:] and ch + cc.shape[1] == self.cfg.in_channels, "c_concat must be [B2, in_channels - C(x), h, w]"
         x = x.contiguous()
         s = sigma.to(device=x.device, dtype=torch.float32).contiguous()
-        ctx = ctx.to(device=x.device, dtype=torch.float32).contiguous()
+        ctx = self._ctx_arg(ctx, x.device, ctx_cached)
         assert s.numel() == b2 and ctx.dim() == 3 and ctx.shape[0] == b2 and ctx.shape[2] == self.cfg.context_dim
         if out is None:
             out = torch.empty((b2, self.cfg.out_channels, h, w), device=x.device, dtype=torch.float32)
@@ -155,8 +192,10 @@ class UNetEngine:
         assert ctx.is_cuda and ctx.dtype == torch.float32 and ctx.is_contiguous() and ctx.dim() == 3 and ctx.shape[0] == 2 * b and ctx.shape[2] == self.cfg.context_dim
         if out is None:
             out = torch.empty((2 * b, self.cfg.out_channels, h, w), device=x.device, dtype=torch.float32)
-        lib.check(self._lib.ldx_unet_denoise_cfg(self._h, lib.ptr(x), float(sigma), lib.ptr(ctx), b, h, w, ctx.shape[1], lib.ptr(out),
-                                                 lib.current_stream_ptr()), "ldx_unet_denoise_cfg")
+        # sigma is a host scalar here: its timestep index is computed with the reference's own torch ops (bit-exact by construction, see timestep_index)
+        t_index = int(self.timestep_index(float(sigma))[0])
+        lib.check(self._lib.ldx_unet_denoise_cfg_t(self._h, lib.ptr(x), float(sigma), t_index, lib.ptr(ctx), b, h, w, ctx.shape[1], lib.ptr(out),
+                                                   lib.current_stream_ptr()), "ldx_unet_denoise_cfg_t")
         return out
 
     def forward(self, x, timesteps, ctx, out=None):
@@ -173,9 +212,17 @@ class UNetEngine:
         return json.loads(buf.value.decode())
 
     def plan_info(self):
+        """launches / algorithmic flops (the reference's arithmetic for this evaluation) / arena bytes of the current plan, plus the flops as EXECUTED
+        (`flops_executed`; smaller than `flops` by `flops_shared` when the plan computes the shared CFG prefix once, ldx_unet_cfg_share)."""
         n, f, a = C.c_int64(), C.c_double(), C.c_int64()
         lib.check(self._lib.ldx_plan_info(self._h, C.byref(n), C.byref(f), C.byref(a)), "ldx_plan_info")
-        return {"launches": n.value, "flops": f.value, "arena_bytes": a.value}
+        ex, sh = C.c_double(), C.c_double()
+        lib.check(self._lib.ldx_plan_flops(self._h, C.byref(ex), C.byref(sh)), "ldx_plan_flops")
+        return {"launches": n.value, "flops": f.value, "arena_bytes": a.value, "flops_executed": ex.value, "flops_shared": sh.value}
+
+    def set_cfg_share(self, on: bool = True):
+        """ldx_unet_cfg_share: denoise_cfg computes the part of the UNet in front of the first cross-attention once for both CFG halves (default on)."""
+        lib.check(self._lib.ldx_unet_cfg_share(self._h, int(on)), "ldx_unet_cfg_share")
 
 
 def _load_state_dict(L, h, state_dict, strip=()):
@@ -545,8 +592,8 @@ class FluxEngine:
     """Flux3.forward behind BaseModel.apply_model with CONST prediction."""
 
     def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16", fp8: bool = False):
-        """fp8=True: the block linears AND (head dim 128) QK^T / PV of the joint attention run on MX fp8 operands (ldx_flux_set_fp8 mode 1; approximate,
-        opt-in, own parity class); fp8="linears": the linears only, attention in 16 bit (mode 2, what fp8 meant through round 4)."""
+        """fp8=True (or "linears"): the block linears run on MX fp8 operands, attention in 16 bit (ldx_flux_set_fp8 mode 1; approximate, opt-in, own parity
+        class).  fp8="attn": explicit opt-in to the less precise full mode (mode 3): at head dim 128 QK^T / PV of the joint attention run on MX fp8 too."""
         self._lib = lib.load()
         self._h = C.c_void_p()
         self.cfg, self.device = cfg, torch.device("cuda", device)
@@ -557,7 +604,8 @@ class FluxEngine:
         c.depth, c.depth_single, c.guidance_embed = cfg.depth, cfg.depth_single_blocks, int(cfg.guidance_embed)
         lib.check(self._lib.ldx_flux_create(C.byref(c), device, C.byref(self._h)), "ldx_flux_create")
         if fp8:
-            lib.check(self._lib.ldx_flux_set_fp8(self._h, 2 if fp8 == "linears" else 1), "ldx_flux_set_fp8")
+            assert fp8 in (True, "linears", "attn"), "fp8 must be False, True / 'linears', or 'attn'"
+            lib.check(self._lib.ldx_flux_set_fp8(self._h, 3 if fp8 == "attn" else 1), "ldx_flux_set_fp8")
         _load_state_dict(self._lib, self._h, state_dict, strip=("model.diffusion_model.",))
         lib.check(self._lib.ldx_finalize(self._h), "ldx_finalize")
         self._pe = {}

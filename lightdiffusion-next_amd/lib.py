@@ -70,8 +70,13 @@ _SIGS = {
     "ldx_finalize": (_i, [_vp]),
     "ldx_unet_denoise": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_denoise_cfg": (_i, [_vp, _vp, C.c_float, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_denoise_cfg_t": (_i, [_vp, _vp, C.c_float, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_denoise_t": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "ldx_unet_timestep": (_i, [_vp, _vp, _i, _vp, _vp]),
     "ldx_unet_denoise_concat": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp]),
     "ldx_unet_context_cache": (_i, [_vp, _i]),
+    "ldx_unet_cfg_share": (_i, [_vp, _i]),
+    "ldx_plan_flops": (_i, [_vp, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "ldx_reload_env": (_i, []),
     "ldx_unet_forward": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "ldx_plan_info": (_i, [_vp, C.POINTER(_i64), C.POINTER(C.c_double), C.POINTER(_i64)]),

@@ -96,6 +96,10 @@ def _run_nonce(nonce=None) -> bytes:
     same path carries another nonce and is ignored by the readers instead of being taken for rank 0's id."""
     import hashlib
     text = nonce if nonce is not None else _os.environ.get("LDX_RCCL_NONCE", "")
+    if not text:
+        # plain torchrun (no bench.py self-launch): derive the name from what torchrun gives every rank of ONE launch — the rendezvous endpoint and run id —
+        # so that a stale id file of a crashed run (other port / run id) can never be taken for this run's
+        text = "|".join(_os.environ.get(k, "") for k in ("MASTER_ADDR", "MASTER_PORT", "TORCHELASTIC_RUN_ID", "TORCHELASTIC_RESTART_COUNT"))
     return hashlib.sha256(text.encode()).digest()[:RUN_NONCE_BYTES]
 
 
@@ -230,6 +234,22 @@ def plan_rank_cpus(allowed, node_of_rank, node_cpus, local_rank: int):
     return pool[lo:hi] if hi > lo else [pool[i % len(pool)]]
 
 
+def masked_rank_cpus(allowed, my_node: int, node_cpus, local_rank: int, local_world: int):
+    """CPUs for a rank that only sees its OWN GPU (per-rank HIP_VISIBLE_DEVICES): the peers' nodes are unknown, so nothing is guessed about them.  The rank's
+    node (my_node, -1 = unknown) is cut into per_node = ceil(local_world / nodes) equal slices and the rank takes slice local_rank % per_node: with the usual
+    even, rank-ordered spread (ranks [k * per_node, (k + 1) * per_node) on node k) the slices of one node's ranks are disjoint by construction — every rank computes
+    the same cut from the same inputs, whatever it believes about the others.  Unknown node: `allowed` cut into local_world slices.  Never empty."""
+    allowed = sorted(set(allowed))
+    pool = sorted(set(node_cpus.get(my_node, [])) & set(allowed)) if my_node is not None and my_node >= 0 else []
+    if pool:
+        n = -(-local_world // max(1, len(node_cpus)))
+        i = local_rank % n
+    else:
+        pool, n, i = allowed, local_world, local_rank
+    lo, hi = i * len(pool) // n, (i + 1) * len(pool) // n
+    return pool[lo:hi] if hi > lo else [pool[i % len(pool)]]
+
+
 def gpu_numa_node(device_index: int) -> int:
     """NUMA node of a visible GPU from sysfs (PCI address from the device properties); -1 when the platform does not say or the index is not
     visible to THIS process (per-rank HIP_VISIBLE_DEVICES: every rank only sees its own GPU as device 0)."""
@@ -261,15 +281,9 @@ def bind_rank_to_numa(local_rank: int, local_world: int):
             pass
     masked = any(os.environ.get(k) for k in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES")) and torch.cuda.device_count() < local_world
     if masked:
-        mine = gpu_numa_node(0)
-        n_nodes = max(1, len(nodes))
-        # peers unknown: assume the launcher spread the ranks evenly over the nodes in rank order (rank r -> node r * n_nodes // local_world)
-        node_of_rank = [(r * n_nodes // local_world) if mine >= 0 else -1 for r in range(local_world)]
-        if mine >= 0:
-            node_of_rank[local_rank] = mine
+        cpus = masked_rank_cpus(allowed, gpu_numa_node(0), nodes, local_rank, local_world)
     else:
-        node_of_rank = [gpu_numa_node(r) for r in range(local_world)]
-    cpus = plan_rank_cpus(allowed, node_of_rank, nodes, local_rank)
+        cpus = plan_rank_cpus(allowed, [gpu_numa_node(r) for r in range(local_world)], nodes, local_rank)
     try:
         os.sched_setaffinity(0, cpus)
     except Exception:

@@ -198,11 +198,18 @@ def publish_state_dict(spec, path: str, seed: int = 1234, dtype=torch.float16) -
     file) and return it as views of the mapping.  Bit-identical to synth_state_dict."""
     import os
     tmp = f"{path}.tmp.{os.getpid()}"
-    sd, buf = _map_state_dict(tmp, spec, dtype, create=True)
-    for k, shp in spec:
-        sd[k].copy_(synth_tensor(k, shp, seed, dtype))
-    del sd, buf                                     # unmap: the shared mapping's pages are the file's pages
-    os.replace(tmp, path)
+    try:
+        sd, buf = _map_state_dict(tmp, spec, dtype, create=True)
+        for k, shp in spec:
+            sd[k].copy_(synth_tensor(k, shp, seed, dtype))
+        del sd, buf                                 # unmap: the shared mapping's pages are the file's pages
+        os.replace(tmp, path)
+    finally:
+        # a failed build must not leave gigabytes behind in tmpfs (the caller falls back to private synthesis and carries on)
+        try:
+            os.unlink(tmp)
+        except FileNotFoundError:
+            pass
     return attach_state_dict(spec, path, dtype)
 
 

@@ -972,11 +972,11 @@ _MX_LINEARS = ("_attn.qkv", "_attn.proj", "_mlp.0", "_mlp.2", ".linear1", ".line
 def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False, mx_attn=None):
     """Flux3.forward + forward_orig (Flux.py:658-778).  x [B,C,h,w] (h, w even), returns the raw model output.
     fb: optional FluxFBCache (approximate mode).  mx: the build's MX fp8 mode — input and weight of every double / single
-    block linear pass through mx_fake_quant (fp32 accumulation, everything else unchanged); mx_attn (default: = mx when the head dim is 128, the build's
-    ldx_flux_set_fp8 mode 1): the joint attention follows mx_attention as well; mx_attn=False = mode 2 (linears only)."""
+    block linear pass through mx_fake_quant (fp32 accumulation, everything else unchanged); mx_attn (default False = ldx_flux_set_fp8 mode 1,
+    linears only): True = mode 3, the joint attention follows mx_attention as well (head dim 128)."""
     w = W(sd)
     if mx_attn is None:
-        mx_attn = bool(mx) and cfg.hidden_size // cfg.num_heads == 128
+        mx_attn = False
 
     def lin(name, t):
         wt = w(name + ".weight")

@@ -22,7 +22,7 @@ for k, shp in spec:        # cheap fill: one small random block tiled (values do
         sd[k] = base.repeat((n + base.numel() - 1) // base.numel())[:n].reshape(shp).half()
 print(f"weights: {ldx.weights.param_count(spec)/1e9:.2f} B params generated in {time.time()-t0:.1f} s", flush=True)
 t0 = time.time()
-FP8 = os.environ.get("LDX_FLUX_FP8", "0") == "1"
+FP8 = {"0": False, "1": "attn", "linears": True}[os.environ.get("LDX_FLUX_FP8", "0")]      # 1: the full mode (linears + attention, bench config 4); linears: attention in 16 bit
 eng = ldx.FluxEngine(cfg, sd, dtype="bf16", fp8=FP8)
 print("fp8 (MX) mode:", FP8)
 del sd

@@ -195,29 +195,44 @@ def test_folded_layernorm_mode_vs_oracle(ldx_lib):
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
 def test_denoise_cfg_equals_denoise_on_the_concatenated_batch(setup, ldx, dt):
     """ldx_unet_denoise_cfg builds calc_cond_batch's [uncond; cond] batch (cond.py:186-226: cat([x] * 2), cat([sigma] * 2)) inside the
-    engine's boundary kernels: bit-identical to ldx_unet_denoise on the torch-concatenated inputs, for B = 1 and B = 3, eager and graph."""
+    engine's boundary kernels.  With the shared prefix off (ldx_unet_cfg_share 0) it is bit-identical to ldx_unet_denoise on the torch-concatenated
+    inputs, for B = 1 and B = 3, eager and graph; with it on (the default: everything in front of the first cross-attention computed once for both
+    halves) the two agree up to the summation order of GroupNorm statistics — and the graph path replays the shared plan bit-identically to its eager run."""
     cfg, sd, g, eng = setup
     e = eng[dt]
     gen = torch.Generator().manual_seed(77)
-    for B in (1, 3):
-        x = torch.randn([B, 4, 16, 16], generator=gen).cuda()
-        ctx = torch.randn([2 * B, 77, cfg.context_dim], generator=gen).cuda()
-        for sigma in (7.25, 0.31):
-            ref = e.denoise(torch.cat([x, x]), torch.full((2 * B,), sigma), ctx).clone()
-            got = e.denoise_cfg(x, sigma, ctx).clone()
-            assert torch.equal(ref, got), f"B {B} sigma {sigma}: {_rel(got, ref.cpu().numpy()):.3e}"
-    x = torch.randn([1, 4, 16, 16], generator=gen).cuda()
-    ctx = torch.randn([2, 77, cfg.context_dim], generator=gen).cuda()
-    xx = torch.cat([x, x]).contiguous()
-    refs = {sg: e.denoise(xx, torch.full((2,), sg).cuda(), ctx).clone() for sg in (5.0, 1.5)}      # eager references, inputs kept alive
-    e.set_graph_mode(True)
+    tol = {"f16": 2e-3, "bf16": 1e-2}[dt]
     try:
-        out = torch.empty([2, 4, 16, 16], device="cuda")
-        for sigma in (5.0, 5.0, 5.0, 1.5, 1.5, 5.0):      # the third call replays the captured graph; the sigma slot is refilled outside it
-            e.denoise_cfg(x, sigma, ctx, out=out)
-            assert torch.equal(out, refs[sigma]), sigma
+        for B in (1, 3):
+            x = torch.randn([B, 4, 16, 16], generator=gen).cuda()
+            ctx = torch.randn([2 * B, 77, cfg.context_dim], generator=gen).cuda()
+            for sigma in (7.25, 0.31):
+                ref = e.denoise(torch.cat([x, x]), torch.full((2 * B,), sigma), ctx).clone()
+                e.set_cfg_share(False)
+                got = e.denoise_cfg(x, sigma, ctx).clone()
+                assert torch.equal(ref, got), f"B {B} sigma {sigma}: {_rel(got, ref.cpu().numpy()):.3e}"
+                e.set_cfg_share(True)
+                shared = e.denoise_cfg(x, sigma, ctx).clone()
+                info = e.plan_info()
+                r = _rel(shared, ref.cpu().numpy())
+                print(f"[{dt}] B {B} sigma {sigma}: shared prefix vs full batch rel-L2 {r:.3e}; executed {info['flops_executed'] / 1e9:.2f} of {info['flops'] / 1e9:.2f} GFLOP")
+                assert r <= tol and info["flops_shared"] > 0 and abs(info["flops_executed"] + info["flops_shared"] - info["flops"]) <= 1e-6 * info["flops"]
+        x = torch.randn([1, 4, 16, 16], generator=gen).cuda()
+        ctx = torch.randn([2, 77, cfg.context_dim], generator=gen).cuda()
+        xx = torch.cat([x, x]).contiguous()
+        for share in (False, True):
+            e.set_cfg_share(share)
+            refs = {sg: (e.denoise_cfg(x, sg, ctx) if share else e.denoise(xx, torch.full((2,), sg).cuda(), ctx)).clone() for sg in (5.0, 1.5)}      # eager references
+            e.set_graph_mode(True)
+            try:
+                out = torch.empty([2, 4, 16, 16], device="cuda")
+                for sigma in (5.0, 5.0, 5.0, 1.5, 1.5, 5.0):      # the third call replays the captured graph; the sigma / index slots are refilled outside it
+                    e.denoise_cfg(x, sigma, ctx, out=out)
+                    assert torch.equal(out, refs[sigma]), (share, sigma)
+            finally:
+                e.set_graph_mode(False)
     finally:
-        e.set_graph_mode(False)
+        e.set_cfg_share(True)
 
 
 def test_cfg_denoiser_uses_the_engine_side_batch(setup, ldx):
@@ -228,9 +243,15 @@ def test_cfg_denoiser_uses_the_engine_side_batch(setup, ldx):
     pos, neg = torch.randn([1, 77, cfg.context_dim], generator=gen), torch.randn([1, 77, cfg.context_dim], generator=gen)
     x = torch.randn([2, 4, 16, 16], generator=gen).cuda()
     den = ldx.sampling.CFGDenoiser(e, pos, neg, 7.0, 2, 16, 16)
-    du, dc = den(x, torch.tensor(3.0))
-    ref = e.denoise(torch.cat([x, x]), torch.full((4,), 3.0), den.ctx)
-    assert torch.equal(torch.cat([du, dc]), ref)
+    e.set_cfg_share(False)
+    try:
+        du, dc = den(x, torch.tensor(3.0))
+        ref = e.denoise(torch.cat([x, x]), torch.full((4,), 3.0), den.ctx)
+        assert torch.equal(torch.cat([du, dc]), ref)
+    finally:
+        e.set_cfg_share(True)
+    du2, dc2 = den(x, torch.tensor(3.0))                       # default: shared prefix
+    assert _rel(torch.cat([du2, dc2]), ref.cpu().numpy()) <= 2e-3
 
 
 @pytest.mark.parametrize("dt,tol", [("f16", 1e-2), ("bf16", 5e-2)])

@@ -53,14 +53,16 @@ def test_flux_head_dim_128_vs_oracle(ldx, ldx_lib):
     assert _rel(out, ref) <= 4e-3
 
 
+@pytest.mark.parametrize("mode", ["linears", "attn"])
 @pytest.mark.parametrize("dt", ["f16", "bf16"])
-def test_flux_mx_fp8_mode_vs_oracle(ldx, ldx_lib, dt):
+def test_flux_mx_fp8_mode_vs_oracle(ldx, ldx_lib, dt, mode):
     """MX fp8 mode (ldx_flux_set_fp8): every block linear runs the block-scaled fp8 MFMA.  The quantiser and the GEMM are
     pinned exactly at the op level (tests/test_mx_gpu.py).  At the model level a quantiser amplifies the 16-bit-vs-fp32
     difference of its input (a value that crosses an e4m3 rounding boundary moves by a whole fp8 step), so two correct
     implementations agree only to a fraction of the quantisation effect itself.  Asserted: engine vs the oracle with the same
     fake-quantised linears rel-L2 <= 3e-2 (measured 2.0e-2 f16 / 2.3e-2 bf16), and engine vs the un-quantised fp32 oracle no
-    worse than that oracle-side quantisation effect (measured 3.1e-2 both) + 25 %: the mode adds no error of its own."""
+    worse than that oracle-side quantisation effect (measured 3.1e-2 both) + 25 %: the mode adds no error of its own.
+    mode "linears" = fp8=True (ldx_flux_set_fp8 1: attention in 16 bit); "attn" = the explicit full mode (3: QK^T / PV on MX fp8 too, head dim 128 here)."""
     cfg = ldx.FluxConfig(in_channels=16, vec_in_dim=64, context_in_dim=128, hidden_size=256, num_heads=2, depth=2,
                          depth_single_blocks=3, axes_dim=(16, 56, 56))
     sd = ldx.weights.synth_state_dict(ldx.weights.flux_state_dict_spec(cfg), seed=5, dtype=torch.float32)
@@ -68,16 +70,16 @@ def test_flux_mx_fp8_mode_vs_oracle(ldx, ldx_lib, dt):
         sd = {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
     else:
         sd = {k: v.to(torch.float16).float() for k, v in sd.items()}
-    eng = ldx.FluxEngine(cfg, sd, device=0, dtype=dt, fp8=True)
+    eng = ldx.FluxEngine(cfg, sd, device=0, dtype=dt, fp8=(True if mode == "linears" else "attn"))
     g = torch.Generator().manual_seed(2)
     x = torch.randn(2, 16, 16, 24, generator=g); ctx = torch.randn(2, 40, 128, generator=g); y = torch.randn(2, 64, generator=g)
     t = torch.tensor([0.7, 0.3]); gd = torch.tensor([3.5, 3.5])
     out = eng.forward(x.cuda(), t.cuda(), ctx.cuda(), y.cuda(), gd.cuda())
     with torch.no_grad():
-        ref_mx = O.flux_forward(sd, cfg, x, t, ctx, y, gd, mx=True)
+        ref_mx = O.flux_forward(sd, cfg, x, t, ctx, y, gd, mx=True, mx_attn=(mode == "attn"))
         ref = O.flux_forward(sd, cfg, x, t, ctx, y, gd)
     r_mx, r_full, q = _rel(out, ref_mx), _rel(out, ref), _rel(ref_mx, ref)
-    print(f"[{dt}] Flux MX fp8: vs MX oracle {r_mx:.3e}; vs fp32 oracle {r_full:.3e} (oracle MX vs fp32 {q:.3e})")
+    print(f"[{dt}] Flux MX fp8 ({mode}): vs MX oracle {r_mx:.3e}; vs fp32 oracle {r_full:.3e} (oracle MX vs fp32 {q:.3e})")
     assert r_mx <= 3e-2
     assert r_full <= 1.25 * q + 5e-3
     # 16-bit engine on the same inputs for scale: the fp8 mode must not be confused with it

@@ -48,7 +48,7 @@ def test_flux_dev_full_depth_both_modes(ldx, ldx_lib):
     x = torch.randn(2, 16, 128, 128, generator=g).cuda(); ctx = torch.randn(2, 256, 4096, generator=g).cuda()
     y = torch.randn(2, 768, generator=g).cuda(); t = torch.tensor([0.6, 0.6]).cuda(); gd = torch.tensor([3.5, 3.5]).cuda()
     outs = {}
-    for fp8 in (False, True):
+    for fp8 in (False, "attn"):          # 16-bit, and the full MX fp8 mode (linears + attention: BASELINE config 4 as bench.py runs it)
         eng = ldx.FluxEngine(cfg, sd, device=0, dtype="bf16", fp8=fp8)       # the mode is fixed at ldx_finalize (weights quantised once)
         a = eng.forward(x, t, ctx, y, gd).clone()
         assert torch.isfinite(a).all(), f"fp8={fp8}: non-finite output"

@@ -121,7 +121,7 @@ def test_fullwidth_flux_properties(ldx, ldx_lib):
                          depth_single_blocks=1, axes_dim=(16, 56, 56))
     sd = ldx.weights.synth_state_dict(ldx.weights.flux_state_dict_spec(cfg), seed=7, dtype=torch.bfloat16)
     e16 = ldx.FluxEngine(cfg, sd, device=0, dtype="bf16")
-    e8 = ldx.FluxEngine(cfg, sd, device=0, dtype="bf16", fp8=True)
+    e8 = ldx.FluxEngine(cfg, sd, device=0, dtype="bf16", fp8="attn")        # the full mode: linears AND attention on MX fp8 (every fp8 kernel at its production shape)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(2, 16, 128, 128, generator=g).cuda(); ctx = torch.randn(2, 256, 4096, generator=g).cuda()
     y = torch.randn(2, 768, generator=g).cuda(); t = torch.tensor([0.6, 0.6]).cuda(); gd = torch.tensor([3.5, 3.5]).cuda()
