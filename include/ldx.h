@@ -184,8 +184,10 @@ int ldx_plan_info(ldx_engine* e, int64_t* n_launches, double* flops, int64_t* ar
  * ResBlock, norm / proj_in, norm1, q|k|v, the first self-attention and its to_out compute every number twice.  ldx_unet_denoise_cfg* (the one entry
  * point that KNOWS the halves share x and sigma) plans those ops on one half and copies the results into the other half's rows where the first
  * cross-attention and the skip connections read them; the outputs equal the concatenated ldx_unet_denoise call up to the summation order of
- * GroupNorm statistics (tile shapes follow the row count).  enable = 0: every op on the full batch (bit-identical to the concatenated call).
- * Default on (environment LDX_CFG_SHARE=0 switches the default off). */
+ * GroupNorm statistics (tile shapes follow the row count).  enable = 0: every op on the full batch (bit-identical to the concatenated call);
+ * 1 (default; environment LDX_CFG_SHARE overrides the default): where it pays — at least LDX_CFG_SHARE_MINROWS (8192) rows per half, below that the
+ * half-batch launches no longer fill the chip (512^2 at bs = 1 measured 5.73 against 5.69 ms per step shared); 2: whenever the model has a
+ * cross-attention for the prefix to end at (tests). */
 int ldx_unet_cfg_share(ldx_engine* e, int enable);
 /* FLOPs of the current plan as EXECUTED in steady state, and the part of ldx_plan_info's algorithmic count that the shared CFG prefix does not
  * execute (algorithmic = executed + shared).  Roofline fractions are quoted on the executed number. */

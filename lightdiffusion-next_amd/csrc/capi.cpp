@@ -305,7 +305,7 @@ int ldx_plan_flops(ldx_engine* e, double* executed, double* shared) {
 int ldx_unet_cfg_share(ldx_engine* e, int enable) {
     if (!e) { set_error("null engine"); return LDX_EINVAL; }
     if (e->impl->kind != KIND_UNET) { set_error("ldx_unet_cfg_share: not a UNet engine"); return LDX_ESTATE; }
-    e->impl->cfg_share = enable != 0;
+    e->impl->cfg_share = enable < 0 ? 0 : (enable > 2 ? 2 : enable);
     return LDX_OK;
 }
 int ldx_profile(ldx_engine* e, int enable, int reset) {

@@ -622,6 +622,7 @@ static bool cp_ws_enabled() { static const bool ws = !(getenv("LDX_CONV_PATCH_WS
 static bool cp_disabled() { static const bool off = getenv("LDX_CONV_PATCH") && atoi(getenv("LDX_CONV_PATCH")) == 0; return off; }
 
 bool conv_patch_ok(const GemmArgs& a) {
+    if (a.dup_rows) return false;          // the dual store of a shared CFG prefix lives in the general output stage (gemm_common.h)
     if (cp_disabled() || a.mode != 1 || a.stride != 1 || a.A2 || a.pad0 || a.f8 || a.C8 || a.ln_c1 || a.geglu || a.rowvec || a.gate || a.splitk > 1) return false;
     const bool narrow = a.N <= 16;      // conv_last / conv_out: 3 or 4 output channels, element-wise epilogue (no residuals), loader-wave kernel with one column tile
     if (!narrow && a.N != 32 && a.N != 64 && a.N != 128) return false;

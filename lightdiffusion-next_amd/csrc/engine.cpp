@@ -106,7 +106,7 @@ static void parallel_for(size_t n, const std::function<void(size_t, size_t)>& fn
 // ---------------------------------------------------------------------------------------------
 Engine::Engine(const ldx_unet_config& c, int dev) : cfg(c), device(dev) {
     dt = (c.compute_dtype == LDX_F16) ? DT_F16 : DT_BF16;
-    cfg_share = !(getenv("LDX_CFG_SHARE") && atoi(getenv("LDX_CFG_SHARE")) == 0);
+    cfg_share = getenv("LDX_CFG_SHARE") ? atoi(getenv("LDX_CFG_SHARE")) : 1;      // 0 off, 1 where it pays (share_for), 2 whenever possible
 }
 Engine::~Engine() {
     (void)hipSetDevice(device);
@@ -622,9 +622,13 @@ void Engine::fuse_gn_stats() {
 // Planner rule for the row-block kernels (rowgemm / xattn_block / ff_block): one workgroup per row block and one workgroup per CU, so below ~3/4 of the
 // CUs the tile GEMMs win (SD1.5 512^2 has 64 row blocks per launch: step 6.14 -> 6.83 ms with the row-block kernels) and smaller problems stay on the
 // separate launches.  LDX_ROWBLOCK_MINWG moves the limit (0: always).
+// In a shared CFG prefix (half the batch: 128 row blocks at 1024^2, bs = 1) the limit is lower: the alternative there is the SAME number of rows on LayerNorm +
+// tile-GEMM launches, which measured slower (LN 12.1 + GEMM 46.3 us against 40.6 for the row-block launch of the full batch; profiles/r06/share_*.txt).
+static bool g_rowblock_prefix = false;          // set by emit_xf / fuse_gn_rowgemm while they emit prefix ops (planning is single-threaded per engine call)
 static bool rowblock_fills_chip(long workgroups) {
     static const long min_wg = getenv("LDX_ROWBLOCK_MINWG") ? atol(getenv("LDX_ROWBLOCK_MINWG")) : 192;
-    return workgroups >= min_wg;
+    static const long min_wg_prefix = getenv("LDX_ROWBLOCK_MINWG_PREFIX") ? atol(getenv("LDX_ROWBLOCK_MINWG_PREFIX")) : 96;
+    return workgroups >= (g_rowblock_prefix ? (min_wg_prefix < min_wg ? min_wg_prefix : min_wg) : min_wg);
 }
 // Row-block GEMM (rowgemm.hip) in place of [LayerNorm +] an N = 320 k, K = 320 projection; false (nothing emitted) when the kernel does not take it
 bool Engine::op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw) {
@@ -645,6 +649,7 @@ bool Engine::op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R,
 // (SpatialTransformer norm + proj_in): the pair becomes one rowgemm launch with the GroupNorm apply as its prologue.  Runs after fuse_gn_stats().
 void Engine::fuse_gn_rowgemm() {
     for (size_t i = 0; i + 1 < ops.size(); ++i) {
+        g_rowblock_prefix = i < prefix_end;
         if (ops[i].kind != OP_GN || ops[i + 1].kind != OP_GEMM) continue;
         const GroupNormArgs& n = ops[i].gn;
         const GemmArgs& g = ops[i + 1].g;
@@ -659,7 +664,9 @@ void Engine::fuse_gn_rowgemm() {
         snprintf(o.klabel, sizeof(o.klabel), "rowgemm<%s,2>", dt == DT_BF16 ? "bf16" : "f16");
         ops[i] = o;
         ops.erase(ops.begin() + (long)i + 1);
+        if (i + 1 < prefix_end) --prefix_end;
     }
+    g_rowblock_prefix = false;
 }
 void Engine::op_ln(const char* name, Act X, Act Y, const NormW& n) {
     Op o{}; o.kind = OP_LN; o.name = name;
@@ -702,6 +709,16 @@ void Engine::op_dup(const Act& a, int rows) {
     o.bytes = 2.0 * 2.0 * (double)rows * a.C;
     snprintf(o.klabel, sizeof(o.klabel), "dup_rows");
     ops.push_back(o);
+}
+
+void Engine::dup_second_half(const DupReq& d) {
+    static const bool copy_only = getenv("LDX_CFG_SHARE_COPY") && atoi(getenv("LDX_CFG_SHARE_COPY")) != 0;      // A/B switch: always the copy launch
+    if (!copy_only && d.producer < ops.size()) {
+        Op& o = ops[d.producer];
+        if (o.kind == OP_GEMM && o.g.C == ptr(d.a) && o.g.ldc == d.a.ld && o.g.M == d.rows && !o.g.geglu && !o.g.C8) { o.g.dup_rows = d.rows; return; }
+        if (o.kind == OP_ROWGEMM && o.rg.Y == ptr(d.a) && o.rg.ldy == d.a.ld && o.rg.M == d.rows) { o.rg.dup_rows = d.rows; return; }
+    }
+    op_dup(d.a, d.rows);
 }
 
 Act Engine::new_act(int rows, int C) {
@@ -747,6 +764,7 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     // Shared CFG prefix (plan(): share): up to the first cross-attention both halves of the batch hold the same values, so norm / proj_in / norm1 / q|k|v /
     // self-attention / to_out of the FIRST transformer block run on the first Bq samples (rows [0, Mq)) only
     int Bq = Bshare > 0 ? Bshare : B, Mq = Bq * H * W;
+    g_rowblock_prefix = Bq != B;
     auto head = [&](const Act& a) { Act v = a; v.rows = Mq; v.owned = false; return v; };      // the first Mq rows of a buffer
     Act t1 = new_act(M, C);
     op_gn("xf.norm", X, t1, Bq, H * W, x.gn, 1e-6f, false);
@@ -792,9 +810,10 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
             op_gemm("xf.o1", head(a), b.o1, head(h), head(h));                   // x += attn1(norm1(x))   (in place)
         if (Bq != B) {
             // the context enters here: from now on the halves differ.  The second half's rows take over the shared results that full-batch ops still read.
-            if (dups) for (const DupReq& dq : *dups) op_dup(dq.a, dq.rows);
-            op_dup(h, Mq);
-            Bq = B; Mq = M;
+            prefix_end = ops.size();                               // every op so far ran on one half of the batch
+            if (dups) for (const DupReq& dq : *dups) dup_second_half(dq);
+            dup_second_half(DupReq{h, Mq, ops.size() - 1});       // the op just emitted (to_out + residual) wrote h
+            Bq = B; Mq = M; g_rowblock_prefix = false;
         }
         // k|v of the context come from the one batched projection emitted at the start of the forward
         const char* kvb = (const char*)((uintptr_t)arena + kv_all_off) + (size_t)b.kv_off * 2;
@@ -848,15 +867,20 @@ void Engine::emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx1
     release(h);
 }
 
+// The batch of the shared CFG prefix for an evaluation (0 = every op on the full batch): a CFG evaluation over ONE latent batch (xB > 0, B2 == 2 xB, no
+// c_concat), a model with a cross-attention for the prefix to end at, and enough rows per half that the prefix ops still fill the chip — below
+// LDX_CFG_SHARE_MINROWS (default 8192: 512^2 at bs = 1 has 4096 and measured 5.73 against 5.69 ms per step shared) nothing is shared.
+int Engine::share_for(int B2, int h, int w, int xB, bool denoise, bool concat) const {
+    static const long share_minrows = getenv("LDX_CFG_SHARE_MINROWS") ? atol(getenv("LDX_CFG_SHARE_MINROWS")) : 8192;
+    if (!cfg_share || !denoise || concat || xB <= 0 || B2 != 2 * xB || (cfg_share == 1 && (long)xB * h * w < share_minrows)) return 0;
+    for (auto& blk : in_blocks) if (blk.has_xf) return xB;
+    return 0;
+}
+
 int Engine::plan(int B2, int h, int w, int Mc, int share) {
-    // share: only meaningful when some block has a cross-attention for the prefix to end at, and B2 = 2 * share
-    if (share > 0) {
-        bool any_xf = false;
-        for (auto& blk : in_blocks) any_xf = any_xf || blk.has_xf;
-        if (!any_xf || B2 != 2 * share) share = 0;
-    }
     // dry run (arena == nullptr) measures the peak; second run binds real pointers
     for (int pass = 0; pass < 2; ++pass) {
+        prefix_end = 0; g_rowblock_prefix = false;
         ops.clear(); flops = 0; free_list.clear(); live.clear(); arena_top = 0; arena_peak = 0;
         if (pass == 1) {
             if (arena && arena_cap < arena_peak_dry) { HIP_OK(hipFree(arena)); arena = nullptr; }
@@ -920,19 +944,19 @@ int Engine::plan(int B2, int h, int w, int Mc, int share) {
         op_conv("conv_in", xin, Bp, h, w, 64, conv_in, 1, h, w, hcur, Act{});
         flops -= 2.0 * Bp * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);   // padded channels are not algorithmic work
         release(xin);
-        if (Bp != B2) pend.push_back({hcur, Bp * h * w});
+        if (Bp != B2) pend.push_back({hcur, Bp * h * w, ops.size() - 1});
         for (auto& blk : in_blocks) {
             ++s;
             Act dst = skip_view(s);
             if (blk.has_down) {
                 op_conv("down", hcur, Bp, Hs[lv], Ws[lv], in_ch[s - 1], blk.down, 2, Hs[lv + 1], Ws[lv + 1], dst, Act{});
                 ++lv;
-                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv]});
+                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv], ops.size() - 1});
             } else if (blk.has_xf) {
                 Act mid = new_act(B2 * Hs[lv] * Ws[lv], blk.res.Cout);
                 emit_res(blk.res, hcur, mid, Bp, Hs[lv], Ws[lv]);
                 if (Bp != B2) {
-                    pend.push_back({mid, Bp * Hs[lv] * Ws[lv]});          // proj_out's residual reads it for every sample
+                    pend.push_back({mid, Bp * Hs[lv] * Ws[lv], ops.size() - 1});          // proj_out's residual reads it for every sample (emit_res ends with the conv that writes it)
                     emit_xf(blk.xf, mid, dst, B2, Hs[lv], Ws[lv], ctx16, Mc, Bp, &pend);
                     Bp = B2; pend.clear();
                 } else {
@@ -941,7 +965,7 @@ int Engine::plan(int B2, int h, int w, int Mc, int share) {
                 release(mid);
             } else {
                 emit_res(blk.res, hcur, dst, Bp, Hs[lv], Ws[lv]);
-                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv]});
+                if (Bp != B2) pend.push_back({dst, Bp * Hs[lv] * Ws[lv], ops.size() - 1});
             }
             hcur = dst;
         }
@@ -1012,7 +1036,7 @@ int Engine::plan(int B2, int h, int w, int Mc, int share) {
         // what the shared prefix saves: every op in front of the first hand-over copy ran on half the batch (the context-only ops are not part of it)
         flops_shared = 0;
         if (share > 0) {
-            for (const Op& o : ops) { if (o.kind == OP_DUP) break; if (!o.ctx_only) flops_shared += o.flops; }
+            for (size_t i = 0; i < prefix_end && i < ops.size(); ++i) if (!ops[i].ctx_only) flops_shared += ops[i].flops;
             flops_shared -= 2.0 * share * h * w * (double)mc * 9.0 * (64 - cfg.in_channels);        // conv_in's padded channels are not algorithmic work (see above)
         }
         fuse_gn_stats();
@@ -1068,7 +1092,7 @@ void Engine::plan_stash() {
     s.B2 = pB2; s.h = ph; s.w = pw; s.M = pM; s.share = pShare; s.ops = std::move(ops); s.flops = flops; s.flops_shared = flops_shared; s.arena = arena; s.arena_cap = arena_cap; s.arena_peak_dry = arena_peak_dry;
     s.gn_ws_off = gn_ws_off; s.prep_xc_off = prep_xc_off; s.kv_all_off = kv_all_off;
     s.d_temb_out = d_temb_out; s.d_e1 = d_e1; s.d_e2 = d_e2; s.d_emb_all = d_emb_all; s.d_eps = d_eps;
-    s.kv_ptr = kv_ptr; s.kv_epoch = kv_epoch; s.g_ctxc = g_ctxc;
+    s.kv_ptr = kv_ptr; s.kv_epoch = kv_epoch; s.kv_stream = kv_stream; s.g_ctxc = g_ctxc;
     s.graph_exec = graph_exec; s.graph_valid = graph_valid; s.warm = warm; s.g_x = g_x; s.g_s = g_s; s.g_ctx = g_ctx; s.g_out = g_out; s.g_den = g_den; s.g_xB = g_xB; s.g_cc = g_cc; s.g_ccn = g_ccn; s.g_t = g_t;
     s.fx_temb = fx_temb; s.fx_gemb = fx_gemb; s.fx_h1 = fx_h1; s.fx_vec = fx_vec; s.fx_svec = fx_svec; s.fx_mod = fx_mod; s.fx_tok = fx_tok;
     s.fb_s0 = fb_s0; s.fb_s1 = fb_s1; s.fb_x = fb_x; s.fb_first = fb_first; s.fb_res = fb_res; s.fb_part = fb_part;
@@ -1093,7 +1117,7 @@ bool Engine::plan_restore(int B2, int h, int w, int Mc, int share) {
         ops = std::move(s.ops); flops = s.flops; flops_shared = s.flops_shared; arena = s.arena; arena_cap = s.arena_cap; arena_peak_dry = s.arena_peak_dry;
         gn_ws_off = s.gn_ws_off; prep_xc_off = s.prep_xc_off; kv_all_off = s.kv_all_off;
         d_temb_out = s.d_temb_out; d_e1 = s.d_e1; d_e2 = s.d_e2; d_emb_all = s.d_emb_all; d_eps = s.d_eps;
-        kv_ptr = s.kv_ptr; kv_epoch = s.kv_epoch; g_ctxc = s.g_ctxc;
+        kv_ptr = s.kv_ptr; kv_epoch = s.kv_epoch; kv_stream = s.kv_stream; g_ctxc = s.g_ctxc;
         graph_exec = s.graph_exec; graph_valid = s.graph_valid; warm = s.warm; g_x = s.g_x; g_s = s.g_s; g_ctx = s.g_ctx; g_out = s.g_out; g_den = s.g_den; g_xB = s.g_xB; g_cc = s.g_cc; g_ccn = s.g_ccn; g_t = s.g_t;
         fx_temb = s.fx_temb; fx_gemb = s.fx_gemb; fx_h1 = s.fx_h1; fx_vec = s.fx_vec; fx_svec = s.fx_svec; fx_mod = s.fx_mod; fx_tok = s.fx_tok;
         fb_s0 = s.fb_s0; fb_s1 = s.fb_s1; fb_x = s.fb_x; fb_first = s.fb_first; fb_res = s.fb_res; fb_part = s.fb_part;
@@ -1253,7 +1277,7 @@ int Engine::run(const float* x, const float* sigma_or_t, const float* ctx, int B
     HIP_OK(hipSetDevice(device));
     // CFG evaluation over one latent batch (ldx_unet_denoise_cfg*: xB > 0 and B2 == 2 xB): the two halves are identical up to the first cross-attention, which
     // the plan then computes once (plan(): share).  LDX_CFG_SHARE=0: every op on the full batch, as the concatenated ldx_unet_denoise call runs it.
-    const int share = (cfg_share && denoise && xB > 0 && B2 == 2 * xB && !c_concat) ? xB : 0;
+    const int share = share_for(B2, h, w, xB, denoise, c_concat != nullptr);
     if (B2 != pB2 || h != ph || w != pw || Mc != pM || share != pShare) {
         HIP_OK(hipStreamSynchronize(st));
         if (pB2 > 0) plan_stash();

@@ -149,8 +149,10 @@ public:
     // first cross-attention (conv_in, the ResBlocks / Downsamples / self-attention up to it) sees identical inputs in both halves and is planned on `share`
     // samples; its results are copied into the second half's rows where the first cross-attention (and the skip connections) need them (OP_DUP).
     int plan(int B2, int h, int w, int Mc, int share = 0);
+    int share_for(int B2, int h, int w, int xB, bool denoise, bool concat) const;
     int pShare = 0;
-    bool cfg_share = true;                 // ldx_unet_cfg_share / LDX_CFG_SHARE: plan CFG evaluations with the shared prefix
+    int cfg_share = 1;                     // ldx_unet_cfg_share / LDX_CFG_SHARE: plan CFG evaluations with the shared prefix (0 never, 1 where it pays, 2 whenever possible)
+    size_t prefix_end = 0;                 // plan(): number of ops in front of the first cross-attention (they ran on `share` samples)
     double flops_shared = 0;               // flops the current plan does NOT execute because of it (the second half's copy of the prefix ops)
     int64_t n_launches() const;
     int64_t n_graph_captures = 0, n_graph_replays = 0;      // ldx_graph_stats (tests: the sampler loops must replay, not re-capture)
@@ -255,9 +257,10 @@ private:
     bool mk_vae_res(const std::string& pre, int Cin, int Cout, ResW& r);
     // Bshare > 0: the ops in front of the first cross-attention run on Bshare samples (see plan()); `dups` = views whose first Bshare * (their own H * W)
     // rows are to be copied into the following rows at that point (plus h itself)
-    struct DupReq { Act a; int rows; };
+    struct DupReq { Act a; int rows; size_t producer; };       // producer: index of the op that writes `a` (its dual store is preferred to a copy launch)
     void emit_xf(const XfW& x, Act X, Act OUT, int B, int H, int W, Act ctx16, int Mc, int Bshare = 0, const std::vector<DupReq>* dups = nullptr);
     void op_dup(const Act& a, int rows);          // rows [0, rows) of view a -> rows [rows, 2 rows)
+    void dup_second_half(const DupReq& d);        // the producer's dual store (GemmArgs / RowGemmArgs::dup_rows) where it has one, else op_dup
 
     // UNet plans of other input shapes seen (multi-scale samplers alternate between two resolutions): launch plan, arena and
     // captured graph are kept per shape, so switching back costs nothing (a re-plan + two eager passes before the graph is
@@ -266,7 +269,7 @@ private:
         int B2 = 0, h = 0, w = 0, M = 0, share = 0; std::vector<Op> ops; double flops = 0, flops_shared = 0; void* arena = nullptr; size_t arena_cap = 0, arena_peak_dry = 0;
         size_t gn_ws_off = 0, prep_xc_off = 0, kv_all_off = 0; float *d_temb_out = nullptr, *d_e1 = nullptr, *d_e2 = nullptr, *d_emb_all = nullptr, *d_eps = nullptr;
         hipGraphExec_t graph_exec = nullptr; bool graph_valid = false, warm = false;
-        const void* kv_ptr = nullptr; uint64_t kv_epoch = 0; bool g_ctxc = false;
+        const void* kv_ptr = nullptr; uint64_t kv_epoch = 0; hipStream_t kv_stream = nullptr; bool g_ctxc = false;
         const void *g_x = nullptr, *g_s = nullptr, *g_ctx = nullptr, *g_out = nullptr; bool g_den = false; int g_xB = 0; const float* g_cc = nullptr; int g_ccn = 0; const float* g_t = nullptr;
         // Flux plans: the per-shape buffers inside the arena and the first-block-cache op ranges
         float *fx_temb = nullptr, *fx_gemb = nullptr, *fx_h1 = nullptr, *fx_vec = nullptr, *fx_svec = nullptr, *fx_mod = nullptr, *fx_tok = nullptr;

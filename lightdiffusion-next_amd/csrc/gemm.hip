@@ -443,11 +443,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
             v[r] = x;
         }
         if (full) {
-            if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+            if (Cp) { const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]); *(uint2*)(Cp + (long)m * p.ldc + n) = pk; if (p.dup_rows) *(uint2*)(Cp + ((long)m + p.dup_rows) * p.ldc + n) = pk; }
             if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
         } else {
             for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(v[r]);
+                if (Cp) { Cp[(long)m * p.ldc + n + r] = from_f32<T>(v[r]); if (p.dup_rows) Cp[((long)m + p.dup_rows) * p.ldc + n + r] = from_f32<T>(v[r]); }
                 if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = v[r];
             }
         }
@@ -507,7 +507,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
                     const float xr = to_f32(from_f32<T>(v[u][c]));      // statistics of the values as stored
                     gs[c] += xr; gq[c] = fmaf(xr, xr, gq[c]);
                 }
-                *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[u][0], v[u][1], v[u][2], v[u][3]);
+                { const uint2 pk = pack4<T>(v[u][0], v[u][1], v[u][2], v[u][3]); *(uint2*)(Cp + (long)m * p.ldc + n) = pk; if (p.dup_rows) *(uint2*)(Cp + ((long)m + p.dup_rows) * p.ldc + n) = pk; }
                 if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[u][0], v[u][1], v[u][2], v[u][3]);
             }
         }
@@ -581,7 +581,10 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
             const int bo = geglu ? 128 : ((N % 160 == 0 && N % 128 != 0) ? 160 : 128);
             const long to = (long)((M + 127) / 128) * ((N + bo - 1) / bo) * S;
             const double cost_old = (double)((to + 511) / 512) * 512.0 * 128.0 * bo / 0.84;
-            if (pp_policy >= 2 || best < 0.95 * cost_old) return {256, best_bn};
+            // (round 6) a ragged 128-wide ping-pong tiling (N = 320: 3 column tiles for 2.5) against 160-wide register-staged tiles that fit one per CU: measured equal
+            // (M 16384 N 320 K 2880: 61.4 vs 60.0 us, profiles/r06/conv_tiles.txt), and only the exact tiling can feed the consumer GroupNorm's statistics
+            const bool ragged_tie = best_bn == 128 && N % 128 != 0 && N % bo == 0 && to <= 256;
+            if (pp_policy >= 2 || (best < 0.95 * cost_old && !ragged_tie)) return {256, best_bn};
         }
     }
     if (geglu) return {128, 128};

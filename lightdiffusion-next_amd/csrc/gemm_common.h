@@ -232,7 +232,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                             v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float xr = to_f32(from_f32<T>(v[r])); gs[r] += xr; gq[r] = fmaf(xr, xr, gq[r]); }
-                if (Cp) *(uint2*)(Cp + m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);
+                if (Cp) { const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]); *(uint2*)(Cp + m * p.ldc + n) = pk; if (p.dup_rows) *(uint2*)(Cp + (m + p.dup_rows) * p.ldc + n) = pk; }
                 if (p.Cf) *(float4*)(p.Cf + m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
             }
 #pragma unroll
@@ -294,7 +294,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                     if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
                                   v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
                     if constexpr (GNS) if (gn) acc[i][j] = (f32x4){to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};      // the 16-bit values the consumer will read, parked in the (dead) accumulator for the statistics pass below
-                    if (Cp) *(uint2*)(Cp + (long)m * p.ldc + n) = pack4<T>(v[0], v[1], v[2], v[3]);     // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
+                    if (Cp) {      // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
+                        const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
+                        *(uint2*)(Cp + (long)m * p.ldc + n) = pk;
+                        if (p.dup_rows) *(uint2*)(Cp + ((long)m + p.dup_rows) * p.ldc + n) = pk;       // second half of a shared CFG prefix (GemmArgs::dup_rows)
+                    }
                     if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
                 } else {
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
@@ -309,7 +313,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                         if (p.oscale != 0.f) x *= p.oscale;
                         if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
                         if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
-                        if (Cp) Cp[(long)m * p.ldc + n + r] = from_f32<T>(x);
+                        if (Cp) { Cp[(long)m * p.ldc + n + r] = from_f32<T>(x); if (p.dup_rows) Cp[((long)m + p.dup_rows) * p.ldc + n + r] = from_f32<T>(x); }
                         if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
                     }
                 }

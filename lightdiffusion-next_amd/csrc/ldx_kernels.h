@@ -80,6 +80,10 @@ struct GemmArgs {
     // gn_nchunk tile rows per batch image — GroupNormArgs::partial's layout, so the GroupNorm skips its statistics pass (one full read of the
     // activation).  Only set by gemm_gn_fuse() below: no split-K / GEGLU / MX output, tile width % gn_cpg == 0, gn_hw % tile height == 0.
     float* gn_partial; int gn_cpg, gn_G, gn_hw, gn_nchunk;
+    // dup_rows != 0: every 16-bit row m of C is ALSO stored at row m + dup_rows (same columns).  The shared CFG prefix (Engine::plan, share): the
+    // ops in front of the first cross-attention run on one half of the [uncond; cond] batch, and what later full-batch ops read of their results
+    // (skip connections, the residual stream) is written for both halves by the producer — no copy launch, no re-read.
+    long dup_rows;
 };
 // Can launch_gemm(a) produce GroupNorm statistics for a consumer GroupNorm(G groups) over [B][HW][a.N]?  If yes, returns the number of
 // tile rows per batch image (the consumer's chunk count) and fills a.gn_* except gn_partial; 0 = not fusable (the GroupNorm runs its own pass).
@@ -192,6 +196,7 @@ struct RowGemmArgs {
     // squares of the 16-bit values it stores, per group, to gn_out[b][chunk = its row block within the image][32][2] (gn_nchunk = HW / rows per block)
     float* gn_out; int gn_nchunk;
     int abl;                       // timing ablations (LDX_RG_ABL, set by the launcher; wrong results): 1 no residual loads, 2 no MFMA loop, 4 no row loads, 8 no stores
+    long dup_rows;                 // != 0: row m of Y is also stored at row m + dup_rows (GemmArgs::dup_rows)
 };
 bool rowgemm_ok(const RowGemmArgs& a);
 void launch_rowgemm(const RowGemmArgs& a, DType dt, hipStream_t s);

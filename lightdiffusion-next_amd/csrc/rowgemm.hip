@@ -222,7 +222,7 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
                 p.gn_out[(((long)bimg * p.gn_nchunk + chunk) * 32 + g0 + gl) * 2 + st] = a;
             }
         }
-        if (!(p.abl & 8)) rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB);
+        if (!(p.abl & 8)) rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB, p.dup_rows);
     }
 }
 

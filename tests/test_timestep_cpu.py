@@ -17,14 +17,24 @@ def test_host_timestep_index_equals_reference_on_all_golden_sigmas(ldx, golden_d
     assert np.array_equal(one, sched["timestep_out"])
 
 
-def test_host_timestep_index_on_scheduler_sigmas_equals_sampling_module(ldx):
+def test_host_timestep_index_on_scheduler_sigmas(ldx):
     """Every sigma a sampler loop can hand over: normal / karras / simple schedules for 1..28 steps (sampling.calculate_sigmas, itself pinned to the
-    reference's tables in test_sampling_host.py) — engine.timestep_index == sampling.ModelSamplingDiscrete.timestep (the reference's expression)."""
+    reference's tables in test_sampling_host.py).  engine.timestep_index == the reference's expression with a correctly rounded logarithm, restated in
+    numpy (host-independent), and == sampling.ModelSamplingDiscrete.timestep (torch's fp32 log: the reference's literal expression) wherever that log is
+    correctly rounded on this host — at most a near-tie may differ, and then only by one index."""
     ms = ldx.sampling.ModelSamplingDiscrete()
+    ls = ms.log_sigmas.numpy()
+    n = differ = 0
     for name in ("normal", "karras", "simple"):
         for steps in (1, 2, 3, 8, 20, 28):
             sig = ldx.sampling.calculate_sigmas(ms, name, steps)
             sig = sig[sig > 0]
-            want = ms.timestep(sig)
             got = ldx.engine.timestep_index(ms.log_sigmas, sig)
-            assert torch.equal(got, want), (name, steps)
+            lg = np.log(sig.numpy().astype(np.float64)).astype(np.float32)
+            want = np.abs(lg[None, :] - ls[:, None]).argmin(axis=0)
+            assert np.array_equal(got.numpy(), want), (name, steps)
+            lit = ms.timestep(sig)
+            d = (got - lit).abs()
+            assert int(d.max()) <= 1, (name, steps)
+            differ += int((d != 0).sum()); n += sig.numel()
+    assert differ <= max(1, n // 100), f"{differ} of {n} scheduler sigmas differ from torch's fp32-log expression"
