@@ -542,6 +542,9 @@ unsigned* Engine::sk_counters() {
     return d_sk_count;
 }
 
+// Split-K workspace of one op: dead as soon as the op's reduce launch has run, so it is freed at once (the next buffer may reuse it).
+size_t Engine::ws_alloc(size_t bytes) { const size_t off = a_alloc(bytes); a_free(off); return off; }
+
 // ---- op emitters ---------------------------------------------------------------------------------
 void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bool geglu, const float* rowvec, int rv_ld, int rpb) {
     Op o{}; o.kind = OP_GEMM; o.name = name;
@@ -552,7 +555,7 @@ void Engine::op_gemm(const char* name, Act A, const LinearW& w, Act C, Act R, bo
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = ptr(C); g.ldc = C.ld; g.Cf = nullptr;
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, geglu);
-    if (g.splitk > 1) { const size_t off = a_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); g.sk_count = sk_counters(); }
+    if (g.splitk > 1) { g.ws = (float*)((uintptr_t)arena + ws_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4)); g.sk_count = sk_counters(); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)g.M * g.K + (double)g.N * g.K + (double)g.M * (geglu ? g.N / 2 : g.N) * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,0>", dt == DT_BF16 ? "bf16" : "f16");
@@ -571,7 +574,7 @@ void Engine::op_conv(const char* name, Act X, int B, int Hin, int Win, int Cin, 
     g.R = R.valid ? ptr(R) : nullptr; g.ldr = R.ld;
     g.C = Y.valid ? ptr(Y) : nullptr; g.ldc = Y.ld; g.Cf = Cf; g.ldcf = ldcf;
     g.splitk = gemm_choose_splitk(g.M, g.N, g.K, false);
-    if (g.splitk > 1) { const size_t off = a_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); g.sk_count = sk_counters(); }
+    if (g.splitk > 1) { g.ws = (float*)((uintptr_t)arena + ws_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4)); g.sk_count = sk_counters(); }
     o.flops = 2.0 * g.M * (double)g.N * g.K;
     o.bytes = 2.0 * ((double)B * Hin * Win * Cin + (double)g.N * g.K + (double)g.M * g.N * (R.valid ? 2 : 1));
     snprintf(o.klabel, sizeof(o.klabel), "gemm_kernel<%s,1>", dt == DT_BF16 ? "bf16" : "f16");

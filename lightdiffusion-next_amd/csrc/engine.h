@@ -191,6 +191,7 @@ private:
     // GroupNorm workspace: gn_ws_rows producer rows per image + GN_FOLD folded rows, x 32 groups x 2 floats (ldx_kernels.h gn_workspace_rows)
     int gn_ws_rows = 256;
     size_t gn_ws_bytes(int B, long HWmax) { gn_ws_rows = (int)gn_workspace_rows(HWmax); return (size_t)B * (gn_ws_rows + GN_FOLD) * 32 * 2 * 4; }
+    size_t ws_alloc(size_t bytes);                        // split-K workspace of one op (engine.cpp)
     void fuse_gn_stats();
     void fuse_gn_rowgemm();                               // GroupNorm (producer statistics) + proj_in -> one rowgemm launch
     bool op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R, int pro, const NormW* nw);          // post-pass over ops: GroupNorms whose input was just written by a fusable GEMM / conv get their statistics from its epilogue

@@ -261,7 +261,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
                 g.f8 = 1; g.A = q.y + (size_t)r0 * q.K; g.lda = q.K; g.SA = q.s + r0; g.sa_ld = RT; g.W = lw.w8; g.SW = lw.sw; g.sw_ld = lw.N;
                 if (!gate) {
                     g.splitk = gemm_choose_splitk(g.M, g.N, g.K / 2, false);
-                    if (g.splitk > 1) { const size_t off = a_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4); g.ws = (float*)((uintptr_t)arena + off); a_free(off); g.sk_count = sk_counters(); }
+                    if (g.splitk > 1) { g.ws = (float*)((uintptr_t)arena + ws_alloc(gemm_sk_ws_floats(g.M, g.N, g.splitk) * 4)); g.sk_count = sk_counters(); }
                 }
                 snprintf(ops.back().klabel, sizeof(ops.back().klabel), "gemm_kernel<mxfp8,0>");
                 if (qo && fuse_gemm_q) {

@@ -531,6 +531,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
         p.gn_partial[(((long)b * p.gn_nchunk + chunk) * p.gn_G + g) * 2 + st] = a;
     }
 }
+
 // geometry of that launch: R row lanes of N / 4 threads (<= 1024 threads, >= 2 * G), chunks of RB rows; 0 = not applicable
 static int splitk_gn_geom(const GemmArgs& a, int HW, int G, int max_chunks, int* R_out) {
     if (a.N % 4 || !a.C || a.N % G || HW <= 0 || a.M % HW) return 0;
@@ -565,13 +566,15 @@ static inline TileSel gemm_tile(int M, int N, int K, bool geglu, int splitk, boo
     // cost = rounds x slots x tile area / rate; LDX_PP: 0 off, 1 model (default), 2 whenever a candidate fills >= 3/4 of the CUs.
     static const int pp_policy = getenv("LDX_PP") ? atoi(getenv("LDX_PP")) : 1;
     static const int pp_mink = getenv("LDX_PP_MINK") ? atoi(getenv("LDX_PP_MINK")) : 1024;
-    if (allow_pp && pp_policy && M >= 1024 && N >= 256 && K >= pp_mink && !(geglu && K < 1024)) {
+    // GEGLU up-projections (N = 8 C, an erf per output pair in the output stage) gain from the 256-wide tiles already at K = 640: M 8192 N 5120 K 640 105 us on
+    // 128 x 128, 97 on 256 x 128, 84 on 256 x 256 (profiles/r06/geglu_tiles.txt)
+    if (allow_pp && pp_policy && M >= 1024 && N >= 256 && (K >= pp_mink || (geglu && K >= 640))) {
         const long S = splitk > 1 ? splitk : 1, mt = (M + 255) / 256;
         double best = 1e30; int best_bn = 0;
         const int cand[5] = {256, 224, 192, 160, 128};
         const double rate[5] = {1.35, plain ? pp_r224 : 0, plain ? pp_r192 : 0, 1.15, 0.92};
         for (int c = 0; c < 5; ++c) {
-            if ((geglu && cand[c] != 128) || rate[c] <= 0) continue;
+            if ((geglu && cand[c] != 128 && cand[c] != 256) || rate[c] <= 0) continue;      // GEGLU pairs value / gate columns inside 64-column slabs: wave tiles of 64 or 128 columns
             const long t = mt * ((N + cand[c] - 1) / cand[c]) * S;
             if (t < 192) continue;                                   // would leave a quarter of the CUs idle
             const double cost = (double)((t + 255) / 256) * 256.0 * 256.0 * cand[c] / rate[c];
@@ -672,7 +675,7 @@ static void launch_gemm_mode(const GemmArgs& a, int S, hipStream_t s) {
             return;
         }
     }
-    if (t.bm == 256 && t.bn > 128 && !a.geglu) launch_gemm_pp(a, t.bn, false, S, DTypeOf<T>::v, s);
+    if (t.bm == 256 && t.bn > 128 && (!a.geglu || t.bn == 256)) launch_gemm_pp(a, t.bn, false, S, DTypeOf<T>::v, s);
     else if (t.bm == 256) launch_gemm_pp(a, 128, false, S, DTypeOf<T>::v, s);
     else if (t.bn == 32) launch_gemm_inst<T, MODE, 128, 32>(a, S, s);
     else if (t.bm == 128 && t.bn == 64) launch_gemm_inst<T, MODE, 128, 64>(a, S, s);

@@ -265,7 +265,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
         const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
         const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
         const float ln_mean = LNF ? lnm[i] : 0.f, ln_rstd = LNF ? lnr[i] : 1.f;
-        if (BN != 128 || !p.geglu) {
+        constexpr bool GEG = BN == 128 || (BN == 256 && !LNF && NR == 1);      // tiles whose wave columns are whole 64-row GEGLU slabs (and that are instantiated for it)
+        if (!GEG || !p.geglu) {
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
                 const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
@@ -318,17 +319,18 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                     }
                 }
             }
-        } else if (BN == 128) {
-            // slab-interleaved GEGLU: j in {0,1} = value columns, j+2 = matching gate columns.
+        } else if constexpr (GEG) {
+            // slab-interleaved GEGLU: within a 64-column slab j in {0,1} = value columns, j+2 = matching gate columns; a wave owns BN / 128 slabs
+#pragma unroll
+            for (int sl = 0; sl < BN / 128; ++sl)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int na = n0 + wn * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
+                const int na = n0 + wn * (BN / 2) + sl * 64 + j * 16 + 4 * g4;        // GEMM column of 'a'
                 const int ng = na + 32;                                // GEMM column of 'g'
                 if (ng >= p.N) continue;
-                const int no = (n0 + wn * 64) / 2 + j * 16 + 4 * g4;  // output column
-                float a[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                constexpr int JG = (BN == 128) ? 2 : 0;
-                float g[4] = {acc[i][j + JG][0], acc[i][j + JG][1], acc[i][j + JG][2], acc[i][j + JG][3]};
+                const int no = (n0 + wn * (BN / 2) + sl * 64) / 2 + j * 16 + 4 * g4;  // output column
+                float a[4] = {acc[i][4 * sl + j][0], acc[i][4 * sl + j][1], acc[i][4 * sl + j][2], acc[i][4 * sl + j][3]};
+                float g[4] = {acc[i][4 * sl + j + 2][0], acc[i][4 * sl + j + 2][1], acc[i][4 * sl + j + 2][2], acc[i][4 * sl + j + 2][3]};
                 if (LNF) {
                     const float4 ca = *(const float4*)(p.ln_c1 + na), cg = *(const float4*)(p.ln_c1 + ng);
                     a[0] = ln_rstd * (a[0] - ln_mean * ca.x); a[1] = ln_rstd * (a[1] - ln_mean * ca.y); a[2] = ln_rstd * (a[2] - ln_mean * ca.z); a[3] = ln_rstd * (a[3] - ln_mean * ca.w);

@@ -16,7 +16,7 @@ static void launch_pp_t(const GemmArgs& a, int bn, bool lnf, int S, hipStream_t 
     } else if (a.mode == 0 && lnf) {      // folded LayerNorm (GemmArgs::ln_c1), no split-K
         if (bn == 160 && !a.geglu) launch_pp_inst<T, 0, 160, true>(a, 1, s); else launch_pp_inst<T, 0, 128, true>(a, 1, s);
     } else if (a.mode == 0) {
-        if (bn == 256 && !a.geglu) launch_pp_inst<T, 0, 256>(a, S, s);
+        if (bn == 256) launch_pp_inst<T, 0, 256>(a, S, s);             // also GEGLU (two 64-column slabs per wave)
         else if (bn == 224 && !a.geglu) launch_pp_inst<T, 0, 224>(a, S, s);
         else if (bn == 192 && !a.geglu) launch_pp_inst<T, 0, 192>(a, S, s);
         else if (bn == 160 && !a.geglu) launch_pp_inst<T, 0, 160>(a, S, s);
@@ -28,7 +28,7 @@ static void launch_pp_t(const GemmArgs& a, int bn, bool lnf, int S, hipStream_t 
     }
 }
 void launch_gemm_pp(const GemmArgs& a, int bn, bool lnf, int S, DType dt, hipStream_t s) {
-    gemm_gn_tile_check(a, 256, (lnf || a.geglu) && bn != 160 ? 128 : bn, S);
+    gemm_gn_tile_check(a, 256, (lnf || (a.geglu && bn != 256)) && bn != 160 ? 128 : bn, S);
     if (dt == DT_BF16) launch_pp_t<__bf16>(a, bn, lnf, S, s); else launch_pp_t<_Float16>(a, bn, lnf, S, s);
 }
 

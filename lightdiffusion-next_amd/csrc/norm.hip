@@ -99,14 +99,47 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, in
     const int tid = threadIdx.x;
     const int b = blockIdx.y;
     const int cpg = p.C / p.G;
+    // Round 6: the kernel is a chain of memory latencies, not a stream — the HW 16384 x C 320 launch took 16.4 us for ONE image and for two (profiles/r06).  What
+    // does not depend on the statistics is therefore requested first: the thread's first four pixel rows and its gamma / beta are in flight while the partials fold.
+    const int tx = tid % TX, ty = tid / TX;
+    const bool act = ty < RY;
+    const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx;
+    T* __restrict__ Y = (T*)p.Y + (long)b * p.HW * p.ldy;
+    const int per = (p.HW + nblk - 1) / nblk;
+    const int pb = blockIdx.x * per, pe = min(p.HW, pb + per);
+    int pix = pb + ty;
+    uint4 u0[4][CH];
+    const bool first4 = act && pix + 3 * RY < pe;
+    if (first4) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) u0[r][k] = *(const uint4*)(X + (long)(pix + r * RY) * p.ldx + (tx + TX * k) * 8);
+    }
+    float4 gam[CH][2], bet[CH][2];
+    if (act) {
+#pragma unroll
+        for (int k = 0; k < CH; ++k) {
+            const int c = (tx + TX * k) * 8;
+            gam[k][0] = *(const float4*)(p.gamma + c); gam[k][1] = *(const float4*)(p.gamma + c + 4);
+            bet[k][0] = *(const float4*)(p.beta + c);  bet[k][1] = *(const float4*)(p.beta + c + 4);
+        }
+    }
     {   // fold the per-chunk partials: 8 slices x 32 groups, fixed order (deterministic)
         const int g = tid & 31, sl = tid >> 5;
         float su = 0.f, sq = 0.f;
         if (g < p.G) {
-            // up to 32 partial rows per thread (nchunk = 256): eight loads in flight at a time, added in row order (same sums as a plain loop) —
+            // up to 32 partial rows per thread (nchunk = 256): sixteen loads in flight at a time, added in row order (same sums as a plain loop) —
             // as a dependent load-add loop this prologue cost ~0.3 us per row and made up most of the kernel at 1024-pixel maps
             const float2* pp = (const float2*)p.partial + ((long)b * p.nchunk) * p.G + g;
             int ck = sl;
+            for (; ck + 120 < p.nchunk; ck += 128) {
+                float2 v[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) v[u] = pp[(long)(ck + 8 * u) * p.G];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) { su += v[u].x; sq += v[u].y; }
+            }
             for (; ck + 56 < p.nchunk; ck += 64) {
                 float2 v[8];
 #pragma unroll
@@ -130,23 +163,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, in
         srstd[tid] = rsqrtf(var + p.eps);
     }
     __syncthreads();
-    const int tx = tid % TX, ty = tid / TX;
-    if (ty >= RY) return;
+    if (!act) return;
     float sc[CH][8], sh[CH][8];
 #pragma unroll
-    for (int k = 0; k < CH; ++k)
+    for (int k = 0; k < CH; ++k) {
+        const float ga[8] = {gam[k][0].x, gam[k][0].y, gam[k][0].z, gam[k][0].w, gam[k][1].x, gam[k][1].y, gam[k][1].z, gam[k][1].w};
+        const float be[8] = {bet[k][0].x, bet[k][0].y, bet[k][0].z, bet[k][0].w, bet[k][1].x, bet[k][1].y, bet[k][1].z, bet[k][1].w};
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const int c = (tx + TX * k) * 8 + e;
             const int g = c / cpg;
-            const float a = srstd[g] * p.gamma[c];
+            const float a = srstd[g] * ga[e];
             sc[k][e] = a;
-            sh[k][e] = p.beta[c] - smean[g] * a;
+            sh[k][e] = be[e] - smean[g] * a;
         }
-    const T* __restrict__ X = (const T*)p.X + (long)b * p.HW * p.ldx;
-    T* __restrict__ Y = (T*)p.Y + (long)b * p.HW * p.ldy;
-    const int per = (p.HW + nblk - 1) / nblk;
-    const int pb = blockIdx.x * per, pe = min(p.HW, pb + per);
+    }
     auto emit = [&](const uint4& u, const int pix, const int k) __attribute__((always_inline)) {
         float f[8];
         unpack8<T>(u, f);
@@ -158,7 +189,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GroupNormArgs p, in
         }
         *(uint4*)(Y + (long)pix * p.ldy + (tx + TX * k) * 8) = pack8<T>(f);
     };
-    int pix = pb + ty;
+    if (first4) {                                     // the rows requested at the top
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int k = 0; k < CH; ++k) emit(u0[r][k], pix + r * RY, k);
+        pix += 4 * RY;
+    }
     for (; pix + 3 * RY < pe; pix += 4 * RY) {      // four pixel rows of loads in flight per thread
         uint4 u[4][CH];
 #pragma unroll

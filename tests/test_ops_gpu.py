@@ -87,6 +87,28 @@ def test_gemm_geglu(L, ldx, dt):
     _check(out, a * F.gelu(gate), dt, what="geglu")
 
 
+@pytest.mark.parametrize("M,C", [(8192, 640), (2048, 1280), (2048 + 96, 1280)])
+def test_gemm_geglu_unet_ff_shapes(L, ldx, M, C):
+    """The FF up-projections of the 64^2 / 32^2 levels (transformer.py:19-70, GEGLU cond/Activation.py:6-31) at their production shapes, where the
+    planner takes 256-wide ping-pong tiles (two 64-column GEGLU slabs per wave, round 6) — bias, ragged last row tile, value / gate pairing."""
+    td, code = DT["bf16"]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    inner = 4 * C
+    A = torch.randn(M, C, device="cuda", generator=g).to(td)
+    Wfull = (torch.randn(2 * inner, C, device="cuda", generator=g) / math.sqrt(C)).to(td)
+    bfull = torch.randn(2 * inner, device="cuda", generator=g)
+    idx = torch.arange(2 * inner, device="cuda")
+    slab, within = idx // 64, idx % 64
+    src = torch.where(within < 32, slab * 32 + within, inner + slab * 32 + (within - 32))
+    Wp, bp = Wfull[src].contiguous(), bfull[src].contiguous()
+    out = torch.zeros(M, inner, device="cuda", dtype=td)
+    ldx.lib.check(L.ldx_op_gemm(_p(A), C, _p(Wp), M, 2 * inner, C, _p(bp), None, 0, 1, 1, None, 0, _p(out), inner, None, 0, code, _st()), "geglu")
+    torch.cuda.synchronize()
+    y = A.float() @ Wfull.float().T + bfull
+    a, gate = y.chunk(2, dim=-1)
+    _check(out, a * F.gelu(gate), "bf16", what=f"geglu M{M} C{C}")
+
+
 CONV_CASES = [
     # B, Hin, Win, Cin, Cout, stride, Hout, Wout, resize, ldx_extra
     (2, 16, 16, 64, 128, 1, 16, 16, 0, 0),
