@@ -1230,6 +1230,9 @@ int Engine::exec_ops(hipStream_t ls, size_t op_begin, size_t op_end, int ctx_sel
                 else if (o.kind == OP_ATTN) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D%d", o.at.B, o.at.H, o.at.Nq, o.at.Mk, o.at.D);
                 else if (o.kind == OP_ATTN_MX) snprintf(sh, sizeof(sh), " B%d H%d N%d M%d D128", o.am.B, o.am.H, o.am.Nq, o.am.Mk);
                 else if (o.kind == OP_GN) snprintf(sh, sizeof(sh), " B%d HW%d C%d", o.gn.B, o.gn.HW, o.gn.C);
+                else if (o.kind == OP_ROWGEMM) snprintf(sh, sizeof(sh), " M%ld N%d K%d", o.rg.M, o.rg.N, o.rg.K);
+                else if (o.kind == OP_XATTN) snprintf(sh, sizeof(sh), " M%ld C%d", (long)o.xa.M, o.xa.C);
+                else if (o.kind == OP_FFBLOCK) snprintf(sh, sizeof(sh), " M%ld C%d", (long)o.fb.M, o.fb.C);
                 else if (o.kind == OP_LN) snprintf(sh, sizeof(sh), " R%d C%d", o.ln.rows, o.ln.C);
                 else if (o.kind == OP_MXQ) snprintf(sh, sizeof(sh), " R%d K%d", o.mq.rows, o.mq.K);
                 else if (o.kind == OP_GEMM2) snprintf(sh, sizeof(sh), " M%d+%d N%d K%d", o.g.M, o.g2.M, o.g.N, o.g.K);

@@ -48,6 +48,22 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     const T* __restrict__ Xp = (const T*)p.X;
     const T* __restrict__ W = (const T*)p.W;
 
+    const int nown = p.N / G::NH;                       // output features of this workgroup: [blockIdx.y * nown, + nown), in passes of 320 (40 per wave)
+    const int npass = nown / 320;
+    constexpr int NKS = RG_C / 32, PD = 3;
+    uint4 wf[PD + 1][3];
+    // Round 6: a wave's loads and stores share one in-order counter, so the first weight fragments of pass p + 1 used to queue behind the output stores of pass p
+    // (and those of pass 0 were only requested after the prologue's row loads and barrier).  They are now requested BEFORE that pass's stores / before the prologue.
+    auto wload = [&](int wrow0_, int l15_, int g4_, int ks, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int t = 0; t < 3; ++t) {
+            const int r = 16 * t + l15_;
+            wf[slot][t] = (r < 40) ? *(const uint4*)(W + (long)(wrow0_ + r) * RG_C + ks * 32 + g4_ * 8) : make_uint4(0, 0, 0, 0);
+        }
+    };
+#pragma unroll
+    for (int ks = 0; ks < PD; ++ks) wload((int)blockIdx.y * nown + wave * 40, l15_0, g4_0, ks, ks);
+
     // ---- prologue: BM rows -> 16-bit A in LDS ----
     if (PRO == 1) { for (int i = tid; i < RG_C; i += 512) { sSc[i] = p.g[i]; sSh[i] = p.b[i]; } }
     if (PRO == 2) {
@@ -130,33 +146,20 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
     __syncthreads();
 
     // ---- N / 320 passes: Y^T[320 pass + 40 wave ..][q] = W rows . A^T, + bias (+ residual) ----
-    const int nown = p.N / G::NH;                       // output features of this workgroup: [blockIdx.y * nown, + nown), in passes of 320 (40 per wave)
-    const int npass = nown / 320;
 #pragma unroll 1
     for (int pass = 0; pass < npass; ++pass) {
         int l15 = l15_0, g4 = g4_0;                       // opaque per pass: otherwise LICM precomputes every per-lane address of the pass (weights,
         asm volatile("" : "+v"(l15), "+v"(g4));           // residual, stores) ahead of the loop and they spill
         const int wrow0 = (int)blockIdx.y * nown + pass * 320 + wave * 40;
-        constexpr int NKS = RG_C / 32, PD = 3;
         f32x4 acc[3][QT];
 #pragma unroll
         for (int t = 0; t < 3; ++t)
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) acc[t][qt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-        uint4 wf[PD + 1][3];
-        auto wload = [&](int ks, int slot) __attribute__((always_inline)) {
-#pragma unroll
-            for (int t = 0; t < 3; ++t) {
-                const int r = 16 * t + l15;
-                wf[slot][t] = (r < 40) ? *(const uint4*)(W + (long)(wrow0 + r) * RG_C + ks * 32 + g4 * 8) : make_uint4(0, 0, 0, 0);
-            }
-        };
-#pragma unroll
-        for (int ks = 0; ks < PD; ++ks) wload(ks, ks);
         if (!(p.abl & 2))
 #pragma unroll
         for (int ks = 0; ks < NKS; ++ks) {
-            if (ks + PD < NKS) wload(ks + PD, (ks + PD) % (PD + 1));
+            if (ks + PD < NKS) wload(wrow0, l15, g4, ks + PD, (ks + PD) % (PD + 1));
             V8 af[QT];
 #pragma unroll
             for (int qt = 0; qt < QT; ++qt) af[qt] = as_v8<T>(*(const uint4*)(sA + (16 * qt + l15) * RG_AROW + (ks * 32 + g4 * 8) * 2));
@@ -221,6 +224,10 @@ __global__ __launch_bounds__(512, 1) void rowgemm_kernel(const RowGemmArgs p) {
                 const int g0 = ((int)blockIdx.y * nown + pass * 320) / cpg;
                 p.gn_out[(((long)bimg * p.gn_nchunk + chunk) * 32 + g0 + gl) * 2 + st] = a;
             }
+        }
+        if (pass + 1 < npass) {                           // the next pass's first weight fragments go out ahead of this pass's stores
+#pragma unroll
+            for (int ks = 0; ks < PD; ++ks) wload(wrow0 + 320, l15, g4, ks, ks);
         }
         if (!(p.abl & 8)) rb_store_rows<T, QT>((T*)p.Y, p.ldy, m0, p.M, (int)blockIdx.y * nown + pass * 320, wave, l15, g4, tid, rr, smem + RG_ABYTES + G::TAB, p.dup_rows);
     }
