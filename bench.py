@@ -693,19 +693,20 @@ def main(argv=None):
         dom = max((k for k in rep if rep[k]["flops"] > 0), key=lambda k: rep[k]["ms"])
         dv = rep[dom]
         dom_tflops = dv["flops"] / (dv["ms"] * 1e-3) / 1e12
-        traffic, traffic_src = None, None
+        traffic, traffic_src, device_kernel = None, None, None
         try:
             import glob
             tj = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*", "traffic.json")))[-1]
             raw = open(tj, "rb").read()
             tjd = json.loads(raw)
             traffic = tjd.get(dom, {}).get("bytes")      # HBM bytes per launch from the committed PMC passes (rocprofv3 --pmc cannot run inside this process)
+            device_kernel = tjd.get(dom, {}).get("device_kernel")      # the mangled name rocprofv3 reports for this launch (profiles/r*/bench_kernel_stats.csv)
             traffic_src = {"file": os.path.relpath(tj, ROOT), "git_blob_sha1": hashlib.sha1(b"blob %d\0" % len(raw) + raw).hexdigest(),
                            "kernel_in_file": dom in tjd, "collected_for": tjd.get("_meta", {}).get("kernel_build")}
         except Exception:
             traffic = None
         step_ms_gpu = statistics.median(gpu_ms)
-        roof = {"bound": "mfma", "kernel": dom, "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
+        roof = {"bound": "mfma", "kernel": dom, "device_kernel": device_kernel, "achieved": round(dom_tflops, 2), "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s",
                 "frac": round(dom_tflops / PEAK_BF16_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "launches_per_step": dv["count"] // nprof, "avg_launch_ms": round(dv["ms"] / dv["count"], 4),
                 "flop_per_launch": round(dv["flops"] / dv["count"] / 1e9, 2),
