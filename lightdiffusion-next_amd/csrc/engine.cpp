@@ -1256,9 +1256,9 @@ int Engine::run_cfg(const float* x, float sigma, const float* ctx, int B, int h,
         HIP_OK(hipMalloc((void**)&d_sigma_cfg, sizeof(float) * 4 * B));
         sigma_cfg_cap = 2 * B;
     }
-    launch_fill_f32(d_sigma_cfg, sigma, 2 * B, st);          // outside the captured graph: the value changes every step
     float* d_t = d_sigma_cfg + sigma_cfg_cap;
-    if (t_index >= 0) launch_fill_f32(d_t, (float)t_index, 2 * B, st);
+    if (t_index >= 0) launch_fill2_f32(d_sigma_cfg, sigma, d_t, (float)t_index, 2 * B, st);          // outside the captured graph: the values change every step
+    else launch_fill_f32(d_sigma_cfg, sigma, 2 * B, st);
     return run(x, d_sigma_cfg, ctx, 2 * B, h, w, Mc, out, true, st, B, nullptr, 0, t_index >= 0 ? d_t : nullptr);
 }
 int Engine::timestep_lookup(const float* sigma_dev, int n, int* out_dev, hipStream_t st) {
@@ -1359,7 +1359,7 @@ int64_t Engine::n_launches() const {
         if (ctx_cache && o.ctx_only) continue;            // steady state of a sampling run: the context's projections are cached
         if (o.kind == OP_ATTN && o.at.nsplit > 1) { n += 2; continue; }      // split keys + merge launch (attn512.hip)
         if (o.kind == OP_GN) n += o.gn.stats_chunks > GN_NCHUNK ? 2 : (o.gn.stats_chunks > 0 ? 1 : 2);      // fold + apply / apply / statistics + apply
-        else n += (o.kind == OP_PREP || (o.kind == OP_GEMM && o.g.splitk > 1 && !gemm_sk_fixup(o.g))) ? 2 : 1;
+        else n += (o.kind == OP_GEMM && o.g.splitk > 1 && !gemm_sk_fixup(o.g)) ? 2 : 1;
     }
     return n;
 }

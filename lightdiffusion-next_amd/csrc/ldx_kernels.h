@@ -263,6 +263,7 @@ void launch_timestep(const float* sigma, const float* log_sigmas, int n_sigmas, 
 // finish: out_nchw[b][c][p] = x_nchw[b][c][p] - eps_nhwc[b][p][c] * sigma[b]   (or raw eps if x == null)
 struct FinishArgs { const float* eps; int ld; const float* x; const float* sigma; float* out; int B, C, HW; int xB; };       // xB as in PrepArgs
 void launch_fill_f32(float* dst, float v, int n, hipStream_t s);
+void launch_fill2_f32(float* a, float va, float* b, float vb, int n, hipStream_t s);      // a[i] = va, b[i] = vb (the sigma and timestep-index slots of a CFG evaluation: one launch)
 // dst[r][0:C) = src[r][0:C) for r in [0, rows): 16-bit elements, both with row stride ld, C % 8 == 0 (the shared CFG prefix's hand-over, Engine::op_dup)
 void launch_dup_rows(const void* src, void* dst, int rows, int C, int ld, DType dt, hipStream_t s);
 // CLIP pooled output: row of last[b] at the first position whose id == eos_id (position 0 if none: torch argmax of an all-zero row),

@@ -13,12 +13,12 @@
 namespace ldx {
 
 template <typename T>
-__global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p) {
+static __device__ __forceinline__ void prep_image_body(const PrepArgs& p, const int block, const int nblocks) {
     // one thread per (b, pixel, 8-channel chunk) of the padded NHWC output
     const int HW = p.H * p.W;
     const int cpp = p.Cpad / 8;
     const long total = (long)p.B * HW * cpp;
-    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+    for (long idx = (long)block * 256 + threadIdx.x; idx < total; idx += (long)nblocks * 256) {
         const int ch = (int)(idx % cpp);
         const long bp = idx / cpp;
         const int pix = (int)(bp % HW), b = (int)(bp / HW);
@@ -63,16 +63,15 @@ static __device__ __forceinline__ int nearest_log_sigma(const float sigma, const
     __syncthreads();
     return t;
 }
-// one block per sample: timestep index (given, or looked up from sigma), then copy the host-built sinusoidal embedding row.
-__global__ __launch_bounds__(256) void prep_time_kernel(const PrepArgs p) {
+// one block per (sample, slice): timestep index (given, or looked up from sigma), then copy the host-built sinusoidal embedding row.
+static __device__ __forceinline__ void prep_time_body(const PrepArgs& p, const int b, const int part, const int nparts) {
     __shared__ float sd[256];
     __shared__ int si[256];
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     int t = p.t_in ? (int)p.t_in[b] : nearest_log_sigma(p.sigma[b], p.log_sigmas, p.n_sigmas, sd, si);
     t = max(0, min(t, p.n_sigmas - 1));
-    // gridDim.y slices: every slice finds the same index, slice 0 writes the embedding row and the timestep, all of them share the emb_layers row copy
+    // nparts slices per sample: every slice finds the same index, slice 0 writes the embedding row and the timestep, all of them share the emb_layers row copy
     // (one workgroup per sample walked its 70 KB in 17 dependent 4-KiB rounds: 14 us of a 14 ms step)
-    const int part = blockIdx.y, nparts = gridDim.y;
     if (part == 0)
         for (int j = tid; j < p.temb_dim; j += 256) p.temb_out[(long)b * p.temb_dim + j] = p.temb_table[(long)t * p.temb_dim + j];
     if (p.emb_table) {                                   // emb_n % 4 == 0 (channel counts are multiples of 64)
@@ -93,12 +92,19 @@ void launch_timestep(const float* sigma, const float* log_sigmas, int n_sigmas, 
     if (n > 0) hipLaunchKernelGGL(timestep_kernel, dim3(n), dim3(256), 0, s, sigma, log_sigmas, n_sigmas, out);
 }
 
+// ONE launch for both halves of the boundary (round 6; they were two): blocks [0, gimg) convert the image, the next B * nparts blocks do the timestep part
+// (the two do not depend on each other).  The kernel keeps the name prep_image_kernel: profiles/analyze_trace.py finds the start of a forward by it.
+template <typename T>
+__global__ __launch_bounds__(256) void prep_image_kernel(const PrepArgs p, const int gimg, const int nparts) {
+    if ((int)blockIdx.x < gimg) prep_image_body<T>(p, blockIdx.x, gimg);
+    else { const int t = (int)blockIdx.x - gimg; prep_time_body(p, t / nparts, t % nparts, nparts); }
+}
 void launch_prep(const PrepArgs& a, DType dt, hipStream_t s) {
     const long total = (long)a.B * a.H * a.W * (a.Cpad / 8);
     int grid = (int)((total + 255) / 256); if (grid > 4096) grid = 4096; if (grid < 1) grid = 1;
-    if (dt == DT_BF16) hipLaunchKernelGGL((prep_image_kernel<__bf16>), dim3(grid), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((prep_image_kernel<_Float16>), dim3(grid), dim3(256), 0, s, a);
-    if (a.temb_out) hipLaunchKernelGGL(prep_time_kernel, dim3(a.B, a.emb_table ? 16 : 1), dim3(256), 0, s, a);
+    const int nparts = a.emb_table ? 16 : 1, gt = a.temb_out ? a.B * nparts : 0;
+    if (dt == DT_BF16) hipLaunchKernelGGL((prep_image_kernel<__bf16>), dim3(grid + gt), dim3(256), 0, s, a, grid, nparts);
+    else hipLaunchKernelGGL((prep_image_kernel<_Float16>), dim3(grid + gt), dim3(256), 0, s, a, grid, nparts);
 }
 
 __global__ __launch_bounds__(256) void finish_kernel(const FinishArgs p) {
@@ -140,6 +146,7 @@ void launch_clip_pooled(const float* last, const int* ids, int B, int T, int E, 
     hipLaunchKernelGGL(clip_pooled_kernel, dim3(B), dim3(256), E * sizeof(float), s, last, ids, T, E, eos_id, proj, out);
 }
 __global__ void fill_f32_kernel(float* dst, float v, int n) { const int i = blockIdx.x * 64 + threadIdx.x; if (i < n) dst[i] = v; }
+__global__ void fill2_f32_kernel(float* a, float va, float* b, float vb, int n) { const int i = blockIdx.x * 64 + threadIdx.x; if (i < n) { a[i] = va; b[i] = vb; } }
 __global__ __launch_bounds__(256) void dup_rows_kernel(const uint4* __restrict__ src, uint4* __restrict__ dst, const long total, const int cpr, const int ld16) {
     // 4 chunks in flight per thread (a copy is pure latency: 10 MB at 1024^2)
     const long stride = (long)gridDim.x * 256;
@@ -157,6 +164,7 @@ void launch_dup_rows(const void* src, void* dst, int rows, int C, int ld, DType,
     long grid = (total + 256 * 4 - 1) / (256 * 4); if (grid > 2048) grid = 2048; if (grid < 1) grid = 1;
     hipLaunchKernelGGL(dup_rows_kernel, dim3((unsigned)grid), dim3(256), 0, s, (const uint4*)src, (uint4*)dst, total, C / 8, ld / 8);
 }
+void launch_fill2_f32(float* a, float va, float* b, float vb, int n, hipStream_t s) { hipLaunchKernelGGL(fill2_f32_kernel, dim3((n + 63) / 64), dim3(64), 0, s, a, va, b, vb, n); }
 void launch_fill_f32(float* dst, float v, int n, hipStream_t s) { hipLaunchKernelGGL(fill_f32_kernel, dim3((n + 63) / 64), dim3(64), 0, s, dst, v, n); }
 void launch_finish(const FinishArgs& a, hipStream_t s) {
     const long total = (long)a.B * a.C * a.HW;
