@@ -275,3 +275,28 @@ def test_ksampler_several_entries_per_side_vs_reference(setup, ldx, golden_dir, 
         r = _rel(out, g[f"ks_{name}"])
         print(f"[{dt}] multi-entry conds, {name}: rel-L2 {r:.3e}")
         assert r <= tol
+
+
+@pytest.mark.parametrize("dt,tol", [("f16", 4e-3), ("bf16", 2.5e-2)])
+def test_shared_cfg_prefix_through_levels_without_attention(ldx, ldx_lib, dt, tol):
+    """A UNet whose first level has NO transformer (unet.py:344-677 allows it: transformer_depth 0): the shared CFG prefix then runs through conv_in, both
+    ResBlocks of level 0 and the Downsample before it meets the first cross-attention at level 1 — three skip tensors plus the ResBlock output and the
+    residual stream reach the second half through their producers' dual stores.  Against the oracle, and shared vs every op on the full batch."""
+    cfg = ldx.UNetConfig(model_channels=64, context_dim=128, transformer_depth=(0, 0, 1, 1, 1, 1, 0, 0), transformer_depth_output=(1, 1, 1, 1, 1, 1, 1, 1, 1, 0, 0, 0))
+    sd = ldx.weights.synth_state_dict(ldx.weights.unet_state_dict_spec(cfg), seed=3)
+    e = ldx.UNetEngine(cfg, sd, device=0, dtype=dt)
+    gen = torch.Generator().manual_seed(1)
+    for (B, h, w) in ((1, 16, 16), (2, 24, 16)):
+        x = torch.randn(B, 4, h, w, generator=gen); ctx = torch.randn(2 * B, 77, 128, generator=gen)
+        with torch.no_grad():
+            ref = O.apply_model(sd, cfg, torch.cat([x, x]), torch.full((2 * B,), 2.5), ctx)
+        e.set_cfg_share(0)
+        full = e.denoise_cfg(x.cuda(), 2.5, ctx.cuda()).clone()
+        n_full = e.plan_info()
+        e.set_cfg_share(2)
+        shared = e.denoise_cfg(x.cuda(), 2.5, ctx.cuda()).clone()
+        n_sh = e.plan_info()
+        r_full, r_sh, d = _rel(full, ref), _rel(shared, ref), _rel(shared, full.cpu())
+        print(f"[{dt}] B {B} {h}x{w}: full vs oracle {r_full:.3e}, shared vs oracle {r_sh:.3e}, shared vs full {d:.3e}; executed {n_sh['flops_executed'] / 1e9:.2f} of {n_sh['flops'] / 1e9:.2f} GFLOP, launches {n_sh['launches']} / {n_full['launches']}")
+        assert r_full <= tol and r_sh <= tol and d <= tol
+        assert n_sh["flops_shared"] > 0.02 * n_sh["flops"] and n_sh["launches"] <= n_full["launches"] + 1       # nothing is copied: the producers store twice
