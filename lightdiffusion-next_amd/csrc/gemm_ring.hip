@@ -90,6 +90,17 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmArgs p) {
     f32x4 acc[MI][NJ];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) acc[0][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // Residual operand requested NOW (round 6; the register-staged kernel has done so since round 2): these launches are chains of a few memory round trips
+    // (operands, residual, stores), and this one hides under the K loop.  Same predicate as the output stage's vector path.
+    uint2 rpre[MI * NJ];
+    const bool use_rpre = p.R != nullptr && p.splitk <= 1 && !p.geglu && !p.C8;
+    if (use_rpre) {
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int m = m0 + wm * 16 + l15, n = n0 + wn * (GR_BN / 2) + j * 16 + 4 * g4;
+            rpre[j] = (m < p.M && n + 3 < p.N) ? *(const uint2*)((const T*)p.R + (long)m * p.ldr + n) : make_uint2(0u, 0u);
+        }
+    }
 
     // prologue: K-tiles 0 .. NS - 2 in flight, wait for K-tile 0
     const int npre = nk < GR_NS - 1 ? nk : GR_NS - 1;
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(512, 1) void gemm_ring_kernel(const GemmArgs p) {
         slot = slot + 1 == GR_NS ? 0 : slot + 1;
     }
     // (the loop ended on a barrier behind every wave's last fragment reads and with no DMA in flight: the ring is free for the output stage's scratch)
-    gemm_epilogue<T, GR_BM, GR_BN, 4, MI, NJ, false, true>(p, acc, m0, n0, wm, wn, l15, g4, 0, 1);
+    gemm_epilogue<T, GR_BM, GR_BN, 4, MI, NJ, false, MI * NJ, true>(p, acc, m0, n0, wm, wn, l15, g4, 0, 1, nullptr, nullptr, rpre, use_rpre);
 }
 
 // Planner rule (gemm_tile asks it): the shapes the register-staged 64 x 64 tiles serve today — fewer than 400 tiles of 128 x 128 and a short K — whose
