@@ -52,4 +52,7 @@ for lv in ["0 (128^2)", "1 (64^2)", "2 (32^2)", "3+mid (16^2)", "0-1 row-block (
         row.append(f"{x:10.3f} -> {y:8.3f}" + " " * 4)
     ta += sa; tb += sb
     print(f"{lv[:14]:14s} " + " ".join(f"{r:>26s}" for r in row) + f" {sa:7.3f} -> {sb:7.3f}")
+# the start-of-round probe carried no shape for the row-block kernels (levels 0 and 1): levels 0 + 1 + that row, comparable in both files
+c01 = lambda t: sum(sum(t.get(lv, {}).values()) for lv in ("0 (128^2)", "1 (64^2)", "0-1 row-block (no shape in this probe)"))
+print(f"{'0 + 1 incl. row-block kernels':70s}" + " " * 52 + f" {c01(a):7.3f} -> {c01(b):7.3f}")
 print(f"{'sum':14s} " + " " * (27 * len(kinds)) + f" {ta:7.3f} -> {tb:7.3f}")
