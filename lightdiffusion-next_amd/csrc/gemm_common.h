@@ -12,6 +12,9 @@ template <> struct DTypeOf<__bf16> { static constexpr DType v = DT_BF16; };
 template <> struct DTypeOf<_Float16> { static constexpr DType v = DT_F16; };
 
 constexpr int BK = 64;
+#ifndef LDX_PP_STAMP
+#define LDX_PP_STAMP(k)        // profiles/ubench/pp_stamp.hip defines it: per-workgroup wall-clock stamps of a tile's phases
+#endif
 // gemm_ring.hip: 64 x 160 LDS-DMA ring tiles for mid-size plain GEMMs; gemm_tile (gemm.hip) asks gemm_ring_ok
 bool gemm_ring_ok(int M, int N, int K, bool plain, int splitk);
 void launch_gemm_ring(const GemmArgs& a, DType dt, hipStream_t s);
@@ -64,9 +67,16 @@ __device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st,
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
 // LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
 template <typename T, int BM, int BN, int WM, int MI, int NJ, bool LNF = false, int NR = 1, bool GNOK = true>
-__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)[MI][NJ], const int m0, const int n0, const int wm, const int wn,
                                               const int l15, const int g4, const int split, const int S,
                                               const float* lnm, const float* lnr, const uint2 (&rpre)[NR], const bool use_rpre) {
+#ifdef LDX_EP_TEST_PLAIN        // profiles/ubench/pp_stamp.hip: the output stage with every optional operand compiled out (how much of its time is code size?)
+    GemmArgs p = p_in;
+    p.rowvec = nullptr; p.gate = nullptr; p.act = 0; p.oscale = 0.f; p.R2 = nullptr; p.Cf = nullptr; p.dup_rows = 0; p.gn_partial = nullptr; p.R = nullptr; p.C8 = nullptr; p.geglu = 0;
+    p.N &= ~3; p.splitk = 1;
+#else
+    const GemmArgs& p = p_in;
+#endif
     // ---- split-K: raw fp32 partials to the workspace.  Without p.sk_count the epilogue happens in splitk_reduce_kernel (a second launch).
     // With it (round 4; gemm_sk_fixup) the LAST workgroup to finish a tile reduces in place and carries on into the fused epilogue below — no
     // reduce launch, and the tile feeds the consumer GroupNorm's statistics like any other.  The recipe is the guide's counter form of the
@@ -143,6 +153,67 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
         }
 #endif
     }
+    // ---- per-column operands through LDS (round 6).  Memory operations of a wave retire in issue order and ONE counter (vmcnt) covers loads and
+    // stores on this target, so a global load issued behind a store cannot be consumed before that store is acknowledged: the output loop "load
+    // bias / gate / residual of a 16 x 16 tile, compute, store" paid one memory round trip per tile — measured with wall-clock stamps inside the kernel
+    // (profiles/ubench/pp_stamp.hip): 10 us for a 256 x 160 tile, 17 us for 256 x 224, 24 us for 256 x 256, i.e. a third of a K = 3072 Flux tile's life
+    // and half of a K = 640 UNet tile's.  Now the folded-LayerNorm c1, bias, per-image vector and gate of the tile's BN columns are fetched once by
+    // the first BN threads into the (dead) operand ring and read back with ds_read (its own counter), and a row group's residuals are requested
+    // together in front of its stores.  Same float operations in the same order per element.
+    const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : 1;
+    const int wrow0 = m0 + wm * (BM / WM), wcol0 = n0 + wn * (BN / 2) + 4 * g4;
+    if ((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) {
+        // the tile straddles images (tiny latents only): per-lane vectors, one element at a time.  Never GEGLU / MX output (no per-image vector) or a
+        // GroupNorm producer (gemm_gn_fuse plans whole tiles of one image).
+        const T* __restrict__ Rs = (const T*)p.R;
+        T* __restrict__ Cs = (T*)p.C;
+#pragma unroll
+        for (int i = 0; i < MI; ++i) {
+            const int m = wrow0 + i * 16 + l15;
+            if (m >= p.M) continue;
+            const float* rv = p.rowvec ? p.rowvec + (long)(m / rpb) * p.rowvec_ld : nullptr;
+            const float* gt = p.gate ? p.gate + (long)(m / rpb) * p.gate_ld : nullptr;
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = wcol0 + 16 * j;
+                for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                    float x = acc[i][j][r];
+                    if (LNF) x = lnr[i] * (x - lnm[i] * p.ln_c1[n + r]);
+                    if (p.bias) x += p.bias[n + r];
+                    if (rv) x += rv[n + r];
+                    if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
+                    else if (p.act == 2) x = gelu_tanh_f(x);
+                    else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
+                    if (gt) x *= gt[n + r];
+                    if (p.oscale != 0.f) x *= p.oscale;
+                    if (Rs) x += to_f32(Rs[(long)m * p.ldr + n + r]);
+                    if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
+                    if (Cs) { Cs[(long)m * p.ldc + n + r] = from_f32<T>(x); if (p.dup_rows) Cs[((long)m + p.dup_rows) * p.ldc + n + r] = from_f32<T>(x); }
+                    if (p.Cf) p.Cf[(long)m * p.ldcf + n + r] = x;
+                }
+            }
+        }
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) char smem_ev[];
+    // [4][BN] floats, 16 KiB into the ring (clear of the statistics stages' first 8 KiB); indexed by the absolute column
+    const float* const ev_c1 = (const float*)(smem_ev + 16384);
+    const float* const ev_bias = ev_c1 + BN, * const ev_rv = ev_c1 + 2 * BN, * const ev_gt = ev_c1 + 3 * BN;
+    {
+        float* const ev = (float*)(smem_ev + 16384);
+        const long img_row = (p.rowvec || p.gate) ? (long)(m0 / rpb) : 0;
+        __syncthreads();            // every wave is past its last fragment read; no DMA is in flight
+        for (int t = threadIdx.x; t < BN; t += WM * 128) {
+            const int n = n0 + t;
+            const bool ok = n < p.N;
+            if (LNF) ev[t] = ok ? p.ln_c1[n] : 0.f;
+            if (p.bias) ev[BN + t] = ok ? p.bias[n] : 0.f;
+            if (p.rowvec) ev[2 * BN + t] = ok ? p.rowvec[img_row * p.rowvec_ld + n] : 0.f;
+            if (p.gate) ev[3 * BN + t] = ok ? p.gate[img_row * p.gate_ld + n] : 0.f;
+        }
+        __syncthreads();
+    }
+    LDX_PP_STAMP(5);
     // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
     if (p.C8) {
         if constexpr ((BN / 2) % 32 == 0) {
@@ -158,7 +229,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
 #pragma unroll
                     for (int r = 0; r < 4; ++r) { v[r] = acc[i][2 * jp][r]; v[4 + r] = acc[i][2 * jp + 1][r]; }
                     if (p.bias && nok) {
-                        const float4 b0 = *(const float4*)(p.bias + n), b1 = *(const float4*)(p.bias + n + 16);
+                        const float4 b0 = *(const float4*)(ev_bias + (n - n0)), b1 = *(const float4*)(ev_bias + (n - n0) + 16);
                         v[0] += b0.x; v[1] += b0.y; v[2] += b0.z; v[3] += b0.w; v[4] += b1.x; v[5] += b1.y; v[6] += b1.z; v[7] += b1.w;
                     }
                     float amax = 0.f;
@@ -202,19 +273,25 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
         extern __shared__ __attribute__((aligned(16))) char smem_epw[];
         float* red = (float*)smem_epw;                  // [WM][BN][2]; the operand tiles are dead behind the barrier
         __syncthreads();
-        int bi[MI];
-#pragma unroll
-        for (int i = 0; i < MI; ++i) bi[i] = (m0 + wm * (BM / WM) + i * 16 + l15) / p.rows_per_batch;
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
             const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
             float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-            const float4 bz = p.bias ? *(const float4*)(p.bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 bz = p.bias ? *(const float4*)(ev_bias + (n - n0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+            uint2 rj[MI], r2j[MI];          // this column tile's residuals, requested together in front of its stores
+            if (Rp) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) rj[i] = *(const uint2*)(Rp + (long)(wrow0 + i * 16 + l15) * p.ldr + n);
+            }
+            if (p.R2) {
+#pragma unroll
+                for (int i = 0; i < MI; ++i) r2j[i] = *(const uint2*)((const T*)p.R2 + (long)(wrow0 + i * 16 + l15) * p.ldr2 + n);
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const long m = m0 + wm * (BM / WM) + i * 16 + l15;
                 float v[4] = {acc[i][j][0] + bz.x, acc[i][j][1] + bz.y, acc[i][j][2] + bz.z, acc[i][j][3] + bz.w};
-                if (p.rowvec) { const float4 b = *(const float4*)(p.rowvec + (long)bi[i] * p.rowvec_ld + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.rowvec) { const float4 b = *(const float4*)(ev_rv + (n - n0)); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
                 if (p.act == 1) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
@@ -225,10 +302,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
                 }
-                if (p.gate) { const float4 b = *(const float4*)(p.gate + (long)bi[i] * p.gate_ld + n); v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                if (p.gate) { const float4 b = *(const float4*)(ev_gt + (n - n0)); v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
                 if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                if (Rp) { float r[4]; unpack4<T>(*(const uint2*)(Rp + m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
-                if (p.R2) { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + m * p.ldr2 + n), r);
+                if (Rp) { float r[4]; unpack4<T>(rj[i], r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+                if (p.R2) { float r[4]; unpack4<T>(r2j[i], r);
                             v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) { const float xr = to_f32(from_f32<T>(v[r])); gs[r] += xr; gq[r] = fmaf(xr, xr, gq[r]); }
@@ -262,55 +339,88 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + l15;
         if (m >= p.M) continue;
-        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
-        const float* gt = p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld : nullptr;
+        const bool rv = p.rowvec != nullptr, gt = p.gate != nullptr;
         const float ln_mean = LNF ? lnm[i] : 0.f, ln_rstd = LNF ? lnr[i] : 1.f;
         constexpr bool GEG = BN == 128 || (BN == 256 && !LNF && NR == 1);      // tiles whose wave columns are whole 64-row GEGLU slabs (and that are instantiated for it)
         if (!GEG || !p.geglu) {
+            uint2 rb[NJ], r2b[NJ];          // this row group's residuals, requested together in front of its stores
+            if (Rp) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = wcol0 + 16 * j;
+                    rb[j] = (NR > 1 && use_rpre) ? rpre[NR > 1 ? i * NJ + j : 0] : n + 3 < p.N ? *(const uint2*)(Rp + (long)m * p.ldr + n) : make_uint2(0u, 0u);
+                }
+            }
+            if (p.R2) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { const int n = wcol0 + 16 * j; r2b[j] = n + 3 < p.N ? *(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n) : make_uint2(0u, 0u); }
+            }
+            // (A) everything in front of the residuals, in place (LDS operands only: no wait on the loads above or on earlier stores)
 #pragma unroll
             for (int j = 0; j < NJ; ++j) {
-                const int n = n0 + wn * (BN / 2) + j * 16 + 4 * g4;
-                if (n >= p.N) continue;
+                const int n = wcol0 + 16 * j;
+                if (n + 3 >= p.N) continue;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                const bool full = (n + 3) < p.N;
-                if (full) {
-                    if (LNF) { const float4 c = *(const float4*)(p.ln_c1 + n);
-                                     v[0] = ln_rstd * (v[0] - ln_mean * c.x); v[1] = ln_rstd * (v[1] - ln_mean * c.y);
-                                     v[2] = ln_rstd * (v[2] - ln_mean * c.z); v[3] = ln_rstd * (v[3] - ln_mean * c.w); }
-                    if (p.bias) { const float4 b = *(const float4*)(p.bias + n); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    if (rv)     { const float4 b = *(const float4*)(rv + n);     v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-                    if (p.act == 1) {
+                if (LNF) { const float4 c = *(const float4*)(ev_c1 + (n - n0));
+                                 v[0] = ln_rstd * (v[0] - ln_mean * c.x); v[1] = ln_rstd * (v[1] - ln_mean * c.y);
+                                 v[2] = ln_rstd * (v[2] - ln_mean * c.z); v[3] = ln_rstd * (v[3] - ln_mean * c.w); }
+                if (p.bias) { const float4 b = *(const float4*)(ev_bias + (n - n0)); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (rv)     { const float4 b = *(const float4*)(ev_rv + (n - n0));   v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+                if (p.act == 1) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
-                    } else if (p.act == 2) {
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] / (1.0f + __expf(-1.702f * v[r]));
+                } else if (p.act == 2) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
-                    } else if (p.act == 3) {
+                    for (int r = 0; r < 4; ++r) v[r] = gelu_tanh_f(v[r]);
+                } else if (p.act == 3) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
-                    }
-                    if (gt)     { const float4 b = *(const float4*)(gt + n);     v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
-                    if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
-                    if (Rp)     { float r[4]; unpack4<T>((NR > 1 && use_rpre) ? rpre[NR > 1 ? i * NJ + j : 0] : *(const uint2*)(Rp + (long)m * p.ldr + n), r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
-                    if (p.R2)   { float r[4]; unpack4<T>(*(const uint2*)((const T*)p.R2 + (long)m * p.ldr2 + n), r);
-                                  v[0] = fmaf(v[0], p.oscale2, r[0]); v[1] = fmaf(v[1], p.oscale2, r[1]); v[2] = fmaf(v[2], p.oscale2, r[2]); v[3] = fmaf(v[3], p.oscale2, r[3]); }
-                    if constexpr (GNS) if (gn) acc[i][j] = (f32x4){to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};      // the 16-bit values the consumer will read, parked in the (dead) accumulator for the statistics pass below
-                    if (Cp) {      // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
-                        const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
-                        *(uint2*)(Cp + (long)m * p.ldc + n) = pk;
-                        if (p.dup_rows) *(uint2*)(Cp + ((long)m + p.dup_rows) * p.ldc + n) = pk;       // second half of a shared CFG prefix (GemmArgs::dup_rows)
-                    }
-                    if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+                    for (int r = 0; r < 4; ++r) v[r] = v[r] > 0.f ? v[r] : 0.2f * v[r];
+                }
+                if (gt)     { const float4 b = *(const float4*)(ev_gt + (n - n0));   v[0] *= b.x; v[1] *= b.y; v[2] *= b.z; v[3] *= b.w; }
+                if (p.oscale != 0.f) { v[0] *= p.oscale; v[1] *= p.oscale; v[2] *= p.oscale; v[3] *= p.oscale; }
+                acc[i][j] = (f32x4){v[0], v[1], v[2], v[3]};
+            }
+            // (B1) the residuals, consumed together BEFORE the row group's first store: one wait per row group (a wait placed behind a store would
+            // also wait for that store)
+            if (Rp) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { float r[4]; unpack4<T>(rb[j], r); acc[i][j][0] += r[0]; acc[i][j][1] += r[1]; acc[i][j][2] += r[2]; acc[i][j][3] += r[3]; }
+            }
+            if (p.R2) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) { float r[4]; unpack4<T>(r2b[j], r);
+                    acc[i][j][0] = fmaf(acc[i][j][0], p.oscale2, r[0]); acc[i][j][1] = fmaf(acc[i][j][1], p.oscale2, r[1]);
+                    acc[i][j][2] = fmaf(acc[i][j][2], p.oscale2, r[2]); acc[i][j][3] = fmaf(acc[i][j][3], p.oscale2, r[3]); }
+            }
+            // (B2) rounding and stores only
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) {
+                const int n = wcol0 + 16 * j;
+                if (n + 3 >= p.N) continue;
+                const float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if constexpr (GNS) if (gn) acc[i][j] = (f32x4){to_f32(from_f32<T>(v[0])), to_f32(from_f32<T>(v[1])), to_f32(from_f32<T>(v[2])), to_f32(from_f32<T>(v[3]))};      // the 16-bit values the consumer will read, parked in the (dead) accumulator for the statistics pass below
+                if (Cp) {      // plain stores: non-temporal ones cost the step 4 % (consumers find the lines in cache)
+                    const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
+                    *(uint2*)(Cp + (long)m * p.ldc + n) = pk;
+                    if (p.dup_rows) *(uint2*)(Cp + ((long)m + p.dup_rows) * p.ldc + n) = pk;       // second half of a shared CFG prefix (GemmArgs::dup_rows)
+                }
+                if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + n) = make_float4(v[0], v[1], v[2], v[3]);
+            }
+            // ragged last columns (N % 4 != 0: ESRGAN's 3-channel output): one element at a time
+            if (p.N & 3) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) {
+                    const int n = wcol0 + 16 * j;
+                    if (n >= p.N || n + 3 < p.N) continue;
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        float x = v[r];
-                        if (LNF) x = ln_rstd * (x - ln_mean * p.ln_c1[n + r]);
-                        if (p.bias) x += p.bias[n + r];
-                        if (rv) x += rv[n + r];
+                        float x = acc[i][j][r];
+                        if (LNF) x = ln_rstd * (x - ln_mean * ev_c1[n - n0 + r]);
+                        if (p.bias) x += ev_bias[n - n0 + r];
+                        if (rv) x += ev_rv[n - n0 + r];
                         if (p.act == 1) x = x / (1.0f + __expf(-1.702f * x));
                         else if (p.act == 2) x = gelu_tanh_f(x);
                         else if (p.act == 3) x = x > 0.f ? x : 0.2f * x;
-                        if (gt) x *= gt[n + r];
+                        if (gt) x *= ev_gt[n - n0 + r];
                         if (p.oscale != 0.f) x *= p.oscale;
                         if (Rp) x += to_f32(Rp[(long)m * p.ldr + n + r]);
                         if (p.R2) x = fmaf(x, p.oscale2, to_f32(((const T*)p.R2)[(long)m * p.ldr2 + n + r]));
@@ -332,12 +442,12 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x4 (&acc)[MI
                 float a[4] = {acc[i][4 * sl + j][0], acc[i][4 * sl + j][1], acc[i][4 * sl + j][2], acc[i][4 * sl + j][3]};
                 float g[4] = {acc[i][4 * sl + j + 2][0], acc[i][4 * sl + j + 2][1], acc[i][4 * sl + j + 2][2], acc[i][4 * sl + j + 2][3]};
                 if (LNF) {
-                    const float4 ca = *(const float4*)(p.ln_c1 + na), cg = *(const float4*)(p.ln_c1 + ng);
+                    const float4 ca = *(const float4*)(ev_c1 + (na - n0)), cg = *(const float4*)(ev_c1 + (ng - n0));
                     a[0] = ln_rstd * (a[0] - ln_mean * ca.x); a[1] = ln_rstd * (a[1] - ln_mean * ca.y); a[2] = ln_rstd * (a[2] - ln_mean * ca.z); a[3] = ln_rstd * (a[3] - ln_mean * ca.w);
                     g[0] = ln_rstd * (g[0] - ln_mean * cg.x); g[1] = ln_rstd * (g[1] - ln_mean * cg.y); g[2] = ln_rstd * (g[2] - ln_mean * cg.z); g[3] = ln_rstd * (g[3] - ln_mean * cg.w);
                 }
                 if (p.bias) {
-                    const float4 ba = *(const float4*)(p.bias + na), bg = *(const float4*)(p.bias + ng);
+                    const float4 ba = *(const float4*)(ev_bias + (na - n0)), bg = *(const float4*)(ev_bias + (ng - n0));
                     a[0] += ba.x; a[1] += ba.y; a[2] += ba.z; a[3] += ba.w;
                     g[0] += bg.x; g[1] += bg.y; g[2] += bg.z; g[3] += bg.w;
                 }
