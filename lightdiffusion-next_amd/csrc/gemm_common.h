@@ -63,6 +63,52 @@ __device__ __forceinline__ void ln_exchange(const f32x4 (&lnacc)[MI], float* st,
     }
 }
 
+// Lean output path (round 6) for the epilogues that make up almost every launch: bias [+ per-image vector] [* gate] [+ residual] -> 16-bit store
+// [+ second store of a shared CFG prefix] [+ GroupNorm statistics], on tiles made of whole 16 x 16 blocks (M % 16 == 0, N % 16 == 0: every predicate is
+// wave-uniform).  The general stage below handles every operand combination in one body — about a hundred executed instructions per 16 x 16 block, and
+// the stage runs at the speed of instruction issue (stamps of profiles/ubench/pp_stamp.hip: a quarter of a K = 3072 tile's life, and neither
+// compiling the unused operands out nor coalescing the stores through an LDS transposition — profiles/experiments/gemm_epilogue_rowwise.h.txt —
+// changed that by more than 2x).  Here the operand kinds that cost registers (residual rows HR, parked statistics HG) are template parameters and the
+// cheap ones (per-image vector, gate, second store) sit behind wave-uniform branches compiled in only with HX: ten to twenty instructions per block.
+// Per element the same float operations in the same order as the general stage.  ev_*: the per-column operands in LDS (tile-relative columns);
+// rall: the tile's residuals, ALL requested at the top of gemm_epilogue (one exposed round trip instead of one per row group: a row group's half
+// microsecond of work hides nothing of a cold line's two).
+template <typename T, int MI, int NJ, bool HR, bool HG, bool HX>
+__device__ __forceinline__ void gemm_epilogue_lean(const GemmArgs& p, f32x4 (&acc)[MI][NJ], const int wrow0, const int wcol0, const int wcu, const int n0, const int l15,
+                                                   const float* ev_bias, const float* ev_rv, const float* ev_gt, const uint2 (&rall)[HR ? MI * NJ : 1]) {
+    T* __restrict__ Cp = (T*)p.C;
+    const bool has_rv = HX && p.rowvec != nullptr, has_gt = HX && p.gate != nullptr, has_dup = HX && p.dup_rows != 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (wrow0 + i * 16 >= p.M) {        // wave-uniform (M % 16 == 0): a row block past M
+            if constexpr (HG) {
+#pragma unroll
+                for (int j = 0; j < NJ; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+            continue;
+        }
+        const long m = wrow0 + i * 16 + l15;
+        T* const crow = Cp + m * p.ldc + wcol0;
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            const int nl = wcol0 - n0 + 16 * j;
+            if (wcu + 16 * j >= p.N) {      // wave-uniform (N % 16 == 0; wcu = the wave's first column): a column block past N
+                if constexpr (HG) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                continue;
+            }
+            const float4 b = *(const float4*)(ev_bias + nl);
+            float v[4] = {acc[i][j][0] + b.x, acc[i][j][1] + b.y, acc[i][j][2] + b.z, acc[i][j][3] + b.w};
+            if (has_rv) { const float4 c = *(const float4*)(ev_rv + nl); v[0] += c.x; v[1] += c.y; v[2] += c.z; v[3] += c.w; }
+            if (has_gt) { const float4 c = *(const float4*)(ev_gt + nl); v[0] *= c.x; v[1] *= c.y; v[2] *= c.z; v[3] *= c.w; }
+            if constexpr (HR) { float r[4]; unpack4<T>(rall[HR ? i * NJ + j : 0], r); v[0] += r[0]; v[1] += r[1]; v[2] += r[2]; v[3] += r[3]; }
+            const uint2 pk = pack4<T>(v[0], v[1], v[2], v[3]);
+            if constexpr (HG) { float r[4]; unpack4<T>(pk, r); acc[i][j] = (f32x4){r[0], r[1], r[2], r[3]}; }      // the 16-bit values the consumer will read, parked for the statistics pass
+            *(uint2*)(crow + 16 * j) = pk;
+            if (has_dup) *(uint2*)(crow + p.dup_rows * p.ldc + 16 * j) = pk;
+        }
+    }
+}
+
 // Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
 // LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
@@ -162,6 +208,22 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     // together in front of its stores.  Same float operations in the same order per element.
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : 1;
     const int wrow0 = m0 + wm * (BM / WM), wcol0 = n0 + wn * (BN / 2) + 4 * g4;
+    // the lean path (gemm_epilogue_lean) and its residual prefetch
+    const bool lean = !LNF && (GNOK || BM == 256) && p.C && p.bias && !p.C8 && !p.geglu && p.act == 0 && p.oscale == 0.f && !p.R2 && !p.Cf && ((p.M | p.N) & 15) == 0 &&
+                      !((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) && !(MI * NJ > 20 && p.gn_partial) && (!p.R || (NR > 1 ? use_rpre : (MI * NJ <= 28 && (GNOK || BM == 256))));
+    constexpr bool RALL = !LNF && NR == 1 && MI * NJ <= 28 && (GNOK || BM == 256);       // (the register-staged MX kernels — GNOK false, BM < 256 — have no room: one spilled VGPR at 128 x 160)       // NR > 1: the caller already requested them ahead of its K loop (rpre).  256-wide tiles (128 accumulators + 64 residual registers) spill: their residual epilogues take the general stage
+    constexpr bool RANY = RALL || (!LNF && NR == MI * NJ);
+    uint2 rall[RALL ? MI * NJ : 1];
+    if constexpr (RALL) {
+        if (lean && p.R) {
+            const T* __restrict__ Rq = (const T*)p.R;
+#pragma unroll
+            for (int i = 0; i < MI; ++i)
+#pragma unroll
+                for (int j = 0; j < NJ; ++j)
+                    rall[i * NJ + j] = (wrow0 + i * 16 < p.M && n0 + wn * (BN / 2) + 16 * j < p.N) ? *(const uint2*)(Rq + (long)(wrow0 + i * 16 + l15) * p.ldr + wcol0 + 16 * j) : make_uint2(0u, 0u);
+        }
+    }
     if ((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) {
         // the tile straddles images (tiny latents only): per-lane vectors, one element at a time.  Never GEGLU / MX output (no per-image vector) or a
         // GroupNorm producer (gemm_gn_fuse plans whole tiles of one image).
@@ -335,6 +397,30 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
         }
         return;
     }
+    bool lean_done = false;
+    if constexpr (!LNF) {
+        if (lean) {
+            const bool hx = p.rowvec || p.gate || p.dup_rows;
+            const float* const eb = ev_bias, * const er = ev_rv, * const eg = ev_gt;
+            const int wcu = n0 + wn * (BN / 2);
+            const uint2 none[1] = {make_uint2(0u, 0u)};
+#define LDX_LEAN(HR_, HG_, HX_, RQ_) gemm_epilogue_lean<T, MI, NJ, HR_, HG_, HX_>(p, acc, wrow0, wcol0, wcu, n0, l15, eb, er, eg, RQ_)
+#define LDX_LEAN_HR(RQ_) do { if (gn) { if constexpr (GNS) { if (hx) LDX_LEAN(true, true, true, RQ_); else LDX_LEAN(true, true, false, RQ_); } } \
+                              else if (hx) LDX_LEAN(true, false, true, RQ_); else LDX_LEAN(true, false, false, RQ_); } while (0)
+            if (Rp) {
+                if constexpr (RALL) LDX_LEAN_HR(rall);
+                else if constexpr (RANY) LDX_LEAN_HR(rpre);
+            } else {
+                if (gn) { if constexpr (GNS) { if (hx) LDX_LEAN(false, true, true, none); else LDX_LEAN(false, true, false, none); } }
+                else if (hx) LDX_LEAN(false, false, true, none);
+                else LDX_LEAN(false, false, false, none);
+            }
+#undef LDX_LEAN_HR
+#undef LDX_LEAN
+            lean_done = true;
+        }
+    }
+    if (!lean_done) {
 #pragma unroll
     for (int i = 0; i < MI; ++i) {
         const int m = m0 + wm * (BM / WM) + i * 16 + l15;
@@ -458,6 +544,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
                 if (p.Cf) *(float4*)(p.Cf + (long)m * p.ldcf + no) = make_float4(v[0], v[1], v[2], v[3]);
             }
         }
+    }
     }
     if constexpr (GNS) if (gn) {
         // per-column sums over the tile's rows: in-lane over i (above), DPP over the 16 lanes that share a column, LDS over the WM wave rows;
