@@ -109,6 +109,41 @@ __device__ __forceinline__ void gemm_epilogue_lean(const GemmArgs& p, f32x4 (&ac
     }
 }
 
+// The same for the MX fp8 output (GemmArgs::C8; bias, optional tanh-GELU as a template parameter): a 32-column block = two adjacent 16-column tiles of
+// one row, spread over the 4 lanes g4 = 0..3.  M % 16 == 0 and N % 32 == 0: whole blocks, wave-uniform predicates.
+template <typename T, int MI, int NJ, int ACT>
+__device__ __forceinline__ void gemm_epilogue_lean_c8(const GemmArgs& p, const f32x4 (&acc)[MI][NJ], const int wrow0, const int wcol0, const int wcu, const int n0,
+                                                      const int l15, const int g4, const float* ev_bias) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+        if (wrow0 + i * 16 >= p.M) continue;        // wave-uniform
+        const long m = wrow0 + i * 16 + l15;
+        char* const drow = (char*)p.C8 + m * p.ldc8 + p.c8_col + wcol0;
+#pragma unroll
+        for (int jp = 0; jp < NJ / 2; ++jp) {
+            if (wcu + 32 * jp >= p.N) continue;     // wave-uniform
+            const int nl = wcol0 - n0 + 32 * jp;
+            const float4 b0 = *(const float4*)(ev_bias + nl), b1 = *(const float4*)(ev_bias + nl + 16);
+            float v[8] = {acc[i][2 * jp][0] + b0.x, acc[i][2 * jp][1] + b0.y, acc[i][2 * jp][2] + b0.z, acc[i][2 * jp][3] + b0.w,
+                          acc[i][2 * jp + 1][0] + b1.x, acc[i][2 * jp + 1][1] + b1.y, acc[i][2 * jp + 1][2] + b1.z, acc[i][2 * jp + 1][3] + b1.w};
+            float amax = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+                if (ACT == 2) v[r] = gelu_tanh_f(v[r]);
+                v[r] = to_f32(from_f32<T>(v[r]));       // the value the 16-bit path would have stored (same input to the quantiser)
+                amax = fmaxf(amax, fabsf(v[r]));
+            }
+            amax = fmaxf(amax, __shfl_xor(amax, 16));
+            amax = fmaxf(amax, __shfl_xor(amax, 32));
+            const int e = mx_scale_e8m0(amax);
+            const float inv = mx_inv_scale(e);
+            *(uint32_t*)(drow + 32 * jp) = mx_pack4(v[0] * inv, v[1] * inv, v[2] * inv, v[3] * inv);
+            *(uint32_t*)(drow + 32 * jp + 16) = mx_pack4(v[4] * inv, v[5] * inv, v[6] * inv, v[7] * inv);
+            if (g4 == 0) { const int kb = (p.c8_col + wcu + 32 * jp) >> 5; ((uint8_t*)p.SC)[((long)(kb >> 2) * p.sc_ld + m) * 4 + (kb & 3)] = (uint8_t)e; }
+        }
+    }
+}
+
 // Output stage shared by the main loops below: split-K partials, MX fp8 output, or the fused 16-bit / fp32 epilogue.
 // Lane (l15, g4) of wave (wm, wn) holds, in acc[i][j][r], row m0 + wm*(BM/WM) + 16 i + l15 and column n0 + wn*(BN/2) + 16 j + 4 g4 + r.
 // LNF: a LayerNorm is folded into this GEMM (GemmArgs::ln_c1): lnm / lnr hold mean and rstd of the lane's MI rows (ln_row_stats).
@@ -279,6 +314,11 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
     if (p.C8) {
         if constexpr ((BN / 2) % 32 == 0) {
+            if (p.bias && (p.act == 0 || p.act == 2) && (p.M & 15) == 0 && (p.N & 31) == 0) {
+                if (p.act == 2) gemm_epilogue_lean_c8<T, MI, NJ, 2>(p, acc, wrow0, wcol0, n0 + wn * (BN / 2), n0, l15, g4, ev_bias);
+                else gemm_epilogue_lean_c8<T, MI, NJ, 0>(p, acc, wrow0, wcol0, n0 + wn * (BN / 2), n0, l15, g4, ev_bias);
+                return;
+            }
 #pragma unroll
             for (int i = 0; i < MI; ++i) {
                 const int m = m0 + wm * (BM / WM) + i * 16 + l15;

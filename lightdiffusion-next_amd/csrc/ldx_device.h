@@ -113,7 +113,7 @@ __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f +
 // tanh-GELU (nn.GELU(approximate="tanh")): 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))) = x * sigmoid(2u)
 __device__ __forceinline__ float gelu_tanh_f(float x) {
     const float u = 0.7978845608028654f * fmaf(0.044715f * x * x, x, x);
-    return x / (1.0f + __expf(-2.0f * u));
+    return x * __builtin_amdgcn_rcpf(1.0f + __expf(-2.0f * u));      // v_rcp_f32 (1 ulp) instead of the ten-instruction IEEE division: the MX output stage of a Flux MLP tile evaluates 96 of these per lane
 }
 
 // Cross-lane reductions on the VALU (DPP within a 16-lane row, v_permlane16/32_swap across rows) instead of
