@@ -357,16 +357,28 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs a, const G
 
 // The split-K reduce launches' epilogue operands for one row and 4 consecutive columns (n % 4 == 0, n + 3 < N)
 struct SkOperands { float4 bias, rv, gate; float r[4], r2[4]; };
+// Round 6: split in two so that the callers can request them WITH the partials (one memory round trip per row instead of two): the per-column part
+// (bias / per-image vector / gate: the same for every row a thread of the GroupNorm-producing reduce owns) and the per-row residuals, raw.
 template <typename T>
-static __device__ __forceinline__ void sk_load_operands(const GemmArgs& p, const long m, const int n, const float* rv, SkOperands& o) {
+static __device__ __forceinline__ void sk_load_col_operands(const GemmArgs& p, const long m, const int n, const float* rv, SkOperands& o) {
     const float* zf = p.ws;                  // readable, 16-byte aligned: what a missing operand loads (and the select below drops)
     const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
     const float4 tb = *(const float4*)(p.bias ? p.bias + n : zf);
     const float4 tr = *(const float4*)(rv ? rv + n : zf);
     const float4 tg = *(const float4*)(p.gate ? p.gate + (long)(m / p.rows_per_batch) * p.gate_ld + n : zf);
-    const uint2 t1 = *(const uint2*)(p.R ? (const void*)((const T*)p.R + m * p.ldr + n) : (const void*)zf);
-    const uint2 t2 = *(const uint2*)(p.R2 ? (const void*)((const T*)p.R2 + m * p.ldr2 + n) : (const void*)zf);
     o.bias = p.bias ? tb : z4; o.rv = rv ? tr : z4; o.gate = p.gate ? tg : make_float4(1.f, 1.f, 1.f, 1.f);
+}
+template <typename T>
+static __device__ __forceinline__ void sk_load_row_operands(const GemmArgs& p, const long m, const int n, uint2& t1, uint2& t2) {
+    const float* zf = p.ws;
+    t1 = *(const uint2*)(p.R ? (const void*)((const T*)p.R + m * p.ldr + n) : (const void*)zf);
+    t2 = *(const uint2*)(p.R2 ? (const void*)((const T*)p.R2 + m * p.ldr2 + n) : (const void*)zf);
+}
+template <typename T>
+static __device__ __forceinline__ void sk_load_operands(const GemmArgs& p, const long m, const int n, const float* rv, SkOperands& o) {
+    uint2 t1, t2;
+    sk_load_col_operands<T>(p, m, n, rv, o);
+    sk_load_row_operands<T>(p, m, n, t1, t2);
     unpack4<T>(t1, o.r); unpack4<T>(t2, o.r2);
 }
 // v -> the stored values, in gemm_epilogue's operation order
@@ -400,6 +412,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
         const int m = (int)(idx / nq), n = (int)(idx % nq) * 4;
         float v[4] = {0.f, 0.f, 0.f, 0.f};
         const bool full = n + 3 < p.N;
+        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
+        SkOperands o;
+        uint2 o1 = make_uint2(0u, 0u), o2 = o1;
+        if (full) { sk_load_col_operands<T>(p, m, n, rv, o); sk_load_row_operands<T>(p, m, n, o1, o2); }      // in flight together with the partials (round 6)
         if (full) {
             // four partial loads in flight at a time (the adds stay in split order: deterministic)
             int sidx = 0;
@@ -420,13 +436,11 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const GemmArgs p) {
                 for (int r = 0; r < 4 && n + r < p.N; ++r) v[r] += w[r];
             }
         }
-        const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
         if (full) {
             // Epilogue operands as UNCONDITIONAL 16 / 8-byte loads (a null operand reads the workspace instead and is discarded by a select): written as
             // `if (p.bias) x += p.bias[n + r]` per element, hipcc emitted one global load + s_waitcnt vmcnt(0) per element and operand — two dozen memory
             // latencies in a row, 13 - 31 us per reduce launch, 0.65 ms of the 1024^2 step (profiles/r05/bench_kernel_stats.csv).  Same operations, same order.
-            SkOperands o;
-            sk_load_operands<T>(p, m, n, rv, o);
+            unpack4<T>(o1, o.r); unpack4<T>(o2, o.r2);
             sk_apply_operands<T>(p, o, v);
         } else
         for (int r = 0; r < 4 && n + r < p.N; ++r) {
@@ -470,6 +484,8 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
     const size_t stride = (size_t)p.M * p.N;
     float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
     if (rl < R) {
+        SkOperands o;                                         // per-column operands: one image per chunk, one column quad per thread -> loaded once
+        sk_load_col_operands<T>(p, row0, n, p.rowvec ? p.rowvec + (long)(row0 / p.rows_per_batch) * p.rowvec_ld : nullptr, o);
         // U rows x SB splits of partial loads in flight per thread.  (Round 5: with one split at a time a chunk of R rows — one row per thread, what the
         // 16^2 / 32^2 levels get — paid one memory latency per split: 20 us for S = 11 at M = 512, as long as the GEMM in front of it.)  The adds stay in
         // split order: same bits as before.
@@ -479,6 +495,9 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
             bool live[U];
 #pragma unroll
             for (int u = 0; u < U; ++u) { live[u] = r + u * R < RB; v[u][0] = v[u][1] = v[u][2] = v[u][3] = 0.f; }
+            uint2 o1[U], o2[U];                               // the rows' residuals, requested with the first partials (round 6: they used to follow the last partial's arrival — a second round trip per row)
+#pragma unroll
+            for (int u = 0; u < U; ++u) { o1[u] = o2[u] = make_uint2(0u, 0u); if (live[u]) sk_load_row_operands<T>(p, row0 + r + u * R, n, o1[u], o2[u]); }
             for (int s0 = 0; s0 < p.splitk; s0 += SB) {
                 float4 t[U][SB];
 #pragma unroll
@@ -498,9 +517,7 @@ __global__ __launch_bounds__(1024) void splitk_reduce_gn_kernel(const GemmArgs p
             for (int u = 0; u < U; ++u) {
                 if (!live[u]) continue;
                 const long m = row0 + r + u * R;
-                const float* rv = p.rowvec ? p.rowvec + (long)(m / p.rows_per_batch) * p.rowvec_ld : nullptr;
-                SkOperands o;                                     // vector loads, no per-element branches (see splitk_reduce_kernel)
-                sk_load_operands<T>(p, m, n, rv, o);
+                unpack4<T>(o1[u], o.r); unpack4<T>(o2[u], o.r2);
                 sk_apply_operands<T>(p, o, v[u]);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -827,7 +844,7 @@ static int gemm2_pp_bn(const GemmArgs& a, const GemmArgs& b) {
 void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) { launch_gemm(b, dt, s); return; }
     if (b.M <= 0 || b.N <= 0) { launch_gemm(a, dt, s); return; }
-    GemmArgs x = a, y = b; x.splitk = y.splitk = 1;
+    GemmArgs x = a, y = b; x.splitk = y.splitk = 1; { static const int epg = getenv("LDX_EP_GENERAL") ? atoi(getenv("LDX_EP_GENERAL")) : 0; x.ep_general = y.ep_general = epg; }
     if (x.f8 && y.f8 && x.M + y.M >= 1024 && y.N >= 256) {       // MX: the two streams of a Flux double block / the two halves of linear1
         const bool c8 = x.C8 || y.C8;
         const int bn = mx_pp_bn((x.M + 255) / 256, (x.M + 127) / 128, x.N, x.K < y.K ? x.K : y.K, 1, c8, (y.M + 255) / 256, (y.M + 127) / 128, y.N);
@@ -841,8 +858,10 @@ void launch_gemm2(const GemmArgs& a, const GemmArgs& b, DType dt, hipStream_t s)
     else { if (a.f8) launch_gemm2_t<_Float16, true>(x, y, s); else launch_gemm2_t<_Float16, false>(x, y, s); }
 }
 
-void launch_gemm(const GemmArgs& a, DType dt, hipStream_t s) {
-    if (a.M <= 0 || a.N <= 0) return;
+static const int ep_general_env = getenv("LDX_EP_GENERAL") ? atoi(getenv("LDX_EP_GENERAL")) : 0;
+void launch_gemm(const GemmArgs& a0, DType dt, hipStream_t s) {
+    if (a0.M <= 0 || a0.N <= 0) return;
+    GemmArgs a = a0; a.ep_general = ep_general_env;
     if (a.mode == 1 && conv_patch_ok(a)) { launch_conv_patch(a, dt, s); return; }      // conv_patch.hip: narrow 3x3 convs with the input patch resident in LDS
     if (dt == DT_BF16) launch_gemm_t<__bf16>(a, s); else launch_gemm_t<_Float16>(a, s);
 }

@@ -244,7 +244,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : 1;
     const int wrow0 = m0 + wm * (BM / WM), wcol0 = n0 + wn * (BN / 2) + 4 * g4;
     // the lean path (gemm_epilogue_lean) and its residual prefetch
-    const bool lean = !LNF && (GNOK || BM == 256) && p.C && p.bias && !p.C8 && !p.geglu && p.act == 0 && p.oscale == 0.f && !p.R2 && !p.Cf && ((p.M | p.N) & 15) == 0 &&
+    const bool lean = !LNF && (GNOK || BM == 256) && !p.ep_general && p.C && p.bias && !p.C8 && !p.geglu && p.act == 0 && p.oscale == 0.f && !p.R2 && !p.Cf && ((p.M | p.N) & 15) == 0 &&
                       !((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) && !(MI * NJ > 20 && p.gn_partial) && (!p.R || (NR > 1 ? use_rpre : (MI * NJ <= 28 && (GNOK || BM == 256))));
     constexpr bool RALL = !LNF && NR == 1 && MI * NJ <= 28 && (GNOK || BM == 256);       // (the register-staged MX kernels — GNOK false, BM < 256 — have no room: one spilled VGPR at 128 x 160)       // NR > 1: the caller already requested them ahead of its K loop (rpre).  256-wide tiles (128 accumulators + 64 residual registers) spill: their residual epilogues take the general stage
     constexpr bool RANY = RALL || (!LNF && NR == MI * NJ);
@@ -314,7 +314,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     // ---- MX fp8 output: a 32-column block = two adjacent 16-column tiles of one row, spread over the 4 lanes g4 = 0..3 ----
     if (p.C8) {
         if constexpr ((BN / 2) % 32 == 0) {
-            if (p.bias && (p.act == 0 || p.act == 2) && (p.M & 15) == 0 && (p.N & 31) == 0) {
+            if (p.bias && !p.ep_general && (p.act == 0 || p.act == 2) && (p.M & 15) == 0 && (p.N & 31) == 0) {
                 if (p.act == 2) gemm_epilogue_lean_c8<T, MI, NJ, 2>(p, acc, wrow0, wcol0, n0 + wn * (BN / 2), n0, l15, g4, ev_bias);
                 else gemm_epilogue_lean_c8<T, MI, NJ, 0>(p, acc, wrow0, wcol0, n0 + wn * (BN / 2), n0, l15, g4, ev_bias);
                 return;
@@ -366,6 +366,8 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     // cannot afford without scratch — those take the column-major stage below (GNW).
     constexpr bool GNS = GNOK && NJ <= 5 && !LNF;
     const bool gn = GNS && p.gn_partial != nullptr;
+    constexpr bool GNL = GNS;                       // (parking in the lean path for the wide tiles too — GNOK && !LNF — spills 150..1260 bytes: two definitions of 128 accumulators meet in front of the statistics pass)
+    const bool gnl = gn;
     // Wide tiles (192..256 columns, NJ = 6..8; round 5): the statistics come from a COLUMN-major output stage instead — for each column tile the lane
     // walks its MI rows, stores them and adds the rounded values in-lane, so an accumulator dies as soon as its column tile is done and nothing is parked
     // (same sums in the same order as the path above: in-lane over i, DPP over the 16 lanes of a column, LDS over the wave rows).  gemm_gn_fuse only plans
@@ -445,13 +447,13 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
             const int wcu = n0 + wn * (BN / 2);
             const uint2 none[1] = {make_uint2(0u, 0u)};
 #define LDX_LEAN(HR_, HG_, HX_, RQ_) gemm_epilogue_lean<T, MI, NJ, HR_, HG_, HX_>(p, acc, wrow0, wcol0, wcu, n0, l15, eb, er, eg, RQ_)
-#define LDX_LEAN_HR(RQ_) do { if (gn) { if constexpr (GNS) { if (hx) LDX_LEAN(true, true, true, RQ_); else LDX_LEAN(true, true, false, RQ_); } } \
+#define LDX_LEAN_HR(RQ_) do { if (gnl) { if constexpr (GNL) { if (hx) LDX_LEAN(true, true, true, RQ_); else LDX_LEAN(true, true, false, RQ_); } } \
                               else if (hx) LDX_LEAN(true, false, true, RQ_); else LDX_LEAN(true, false, false, RQ_); } while (0)
             if (Rp) {
                 if constexpr (RALL) LDX_LEAN_HR(rall);
                 else if constexpr (RANY) LDX_LEAN_HR(rpre);
             } else {
-                if (gn) { if constexpr (GNS) { if (hx) LDX_LEAN(false, true, true, none); else LDX_LEAN(false, true, false, none); } }
+                if (gnl) { if constexpr (GNL) { if (hx) LDX_LEAN(false, true, true, none); else LDX_LEAN(false, true, false, none); } }
                 else if (hx) LDX_LEAN(false, false, true, none);
                 else LDX_LEAN(false, false, false, none);
             }
@@ -586,7 +588,7 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
         }
     }
     }
-    if constexpr (GNS) if (gn) {
+    if constexpr (GNL) if (gnl && (lean_done || NJ <= 5)) {
         // per-column sums over the tile's rows: in-lane over i (above), DPP over the 16 lanes that share a column, LDS over the WM wave rows;
         // then one thread per (group of the tile, statistic) adds its gn_cpg columns in a fixed order -> deterministic, no atomics
         extern __shared__ __attribute__((aligned(16))) char smem_ep[];

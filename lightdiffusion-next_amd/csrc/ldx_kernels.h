@@ -84,6 +84,7 @@ struct GemmArgs {
     // ops in front of the first cross-attention run on one half of the [uncond; cond] batch, and what later full-batch ops read of their results
     // (skip connections, the residual stream) is written for both halves by the producer — no copy launch, no re-read.
     long dup_rows;
+    int ep_general;                // experiment switch (LDX_EP_GENERAL=1, set by launch_gemm): the general output stage for every epilogue (A/B against the lean paths of gemm_common.h)
 };
 // Can launch_gemm(a) produce GroupNorm statistics for a consumer GroupNorm(G groups) over [B][HW][a.N]?  If yes, returns the number of
 // tile rows per batch image (the consumer's chunk count) and fills a.gn_* except gn_partial; 0 = not fusable (the GroupNorm runs its own pass).
