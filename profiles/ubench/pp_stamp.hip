@@ -65,6 +65,7 @@ int main(int argc, char** argv) {
     CK(hipMemset(SA, 0x70, (size_t)(K / 128 + 1) * M * 4)); CK(hipMemset(SW, 0x70, (size_t)(K / 128 + 1) * N * 4)); CK(hipMemset(bias, 0, N * 4)); CK(hipMemset(C, 0, (size_t)M * N * 2));
     GemmArgs a; memset(&a, 0, sizeof(a));
     a.A = A; a.lda = K; a.W = W; a.M = M; a.N = N; a.K = K; a.bias = bias; a.C = C; a.ldc = N; a.rows_per_batch = M; a.splitk = 1;
+    a.ep_general = getenv("LDX_EP_GENERAL") ? atoi(getenv("LDX_EP_GENERAL")) : 0;      // 1: the general output stage (what launch_gemm's switch selects)
     if (resid) { a.R = C; a.ldr = N; }
     if (geglu || lngeglu) { a.geglu = 1; a.ldc = N / 2; }
     if (lngeglu) { a.ln_c1 = bias; a.ln_eps = 1e-5f; }
