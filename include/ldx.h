@@ -263,7 +263,9 @@ int ldx_flux_fbcache(ldx_engine* e, float residual_diff_threshold);
 int ldx_flux_fbcache_stats(ldx_engine* e, int64_t* hits, int64_t* misses);
 /* MX fp8 mode (BASELINE config 4 "fp8 MFMA"; opt-in, approximate, own parity class): the linears of the double / single
  * blocks run the block-scaled 16x16x128 MFMA on e4m3fn operands with one E8M0 scale per 32 consecutive k (weights
- * quantised once in ldx_finalize, activations per forward); everything else stays 16-bit.  Call before ldx_finalize;
+ * quantised once in ldx_finalize, activations per forward), and the batched adaLN modulation projections (img_mod / txt_mod /
+ * modulation / final adaLN: one skinny GEMM) read MX weights against the MX-quantised SiLU(vec) (round 6; LDX_FLUX_MOD_FP8=0 keeps them
+ * 16-bit); everything else stays 16-bit.  Call before ldx_finalize;
  * needs hidden_size % 128 == 0 and mlp_hidden % 128 == 0.  The reference runs Flux from Q8_0 weights (also 32-element
  * blocks, src/Quantize/Quantizer.py:94-112) dequantised to 16-bit, i.e. W8A16; this mode is W8A8.
  * enable = 1 (2 is an alias): the linears only; attention stays 16-bit.

@@ -120,6 +120,8 @@ int Engine::finalize_flux() {
         for (FluxDoubleW& d : fx_double)
             for (FluxStreamW* s : {&d.img, &d.txt}) q = q && mx_quantize_weight(s->qkv) && mx_quantize_weight(s->proj) && mx_quantize_weight(s->mlp0) && mx_quantize_weight(s->mlp2);
         for (FluxSingleW& s : fx_single) q = q && mx_quantize_weight(s.lin1_qkv) && mx_quantize_weight(s.lin1_mlp) && mx_quantize_weight(s.lin2);
+        static const bool mod8 = !(getenv("LDX_FLUX_MOD_FP8") && atoi(getenv("LDX_FLUX_MOD_FP8")) == 0);      // round 6: the batched adaLN modulation projections too (6.4 -> 3.2 GB streamed per forward)
+        if (mod8) q = q && mx_quantize_weight(fx_mod_all);
         if (!q || hipDeviceSynchronize() != hipSuccess) { set_error(std::string("MX weight quantisation failed: ") + hipGetErrorString(hipGetLastError())); return LDX_EHIP; }
     }
     finalized = true;
@@ -176,6 +178,7 @@ int Engine::plan_flux(int B, int h, int w, int Lt) {
         skinny("fx.vector_in.1", OP_SKINNY, fx_h1, C, fx_vec1, fx_vec, 0, 1);
         { Op o{}; o.kind = OP_FX_SILU; o.name = "fx.silu_vec"; o.p0 = fx_vec; o.p1 = fx_svec; o.i0 = B * C; ops.push_back(o); }
         skinny("fx.modulation_all", OP_SKINNY, fx_svec, C, fx_mod_all, fx_mod, 0, 0);
+        if (fx_fp8 && fx_mod_all.w8) { SkinnyArgs& k = ops.back().sk; k.W8 = fx_mod_all.w8; k.SW = fx_mod_all.sw; k.sw_ld = fx_mod_all.N; }
 
         // joint token buffer and inputs
         Act X = new_act(B * L, C);

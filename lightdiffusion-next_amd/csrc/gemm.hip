@@ -926,10 +926,111 @@ __global__ __launch_bounds__(256) void skinny_kernel(const SkinnyArgs p) {
     }
 }
 
+// The same with MX fp8 weights (SkinnyArgs::W8): the activation block goes through the MX rule while it is staged — per 32 consecutive k: amax, E8M0 scale,
+// e4m3 round-to-nearest-even, back to fp32 (oracle mx_fake_quant; the value a block-scaled MFMA would see) — and every lane streams 16 weights per 16-byte load,
+// dequantised with the scale byte of their block.  fp32 accumulation.  HBM-bound like the 16-bit kernel, at half the bytes.
+constexpr int SKM_RG = 4;
+__global__ __launch_bounds__(256) void skinny_mx_kernel(const SkinnyArgs p) {
+    extern __shared__ float sx[];                          // [mrows][K]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nkb = p.K >> 5;
+    for (int mb = 0; mb < p.M; mb += 4) {
+        const int mr = min(4, p.M - mb);
+        __syncthreads();
+        for (int blk = threadIdx.x; blk < mr * nkb; blk += 256) {      // one thread per 32-element block
+            const int mi = blk / nkb, kb = blk - mi * nkb;
+            const float* src = p.x + (long)(mb + mi) * p.ldx + kb * 32;
+            float f[32];
+            float amax = 0.f;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float4 t = *(const float4*)(src + 4 * c);
+                f[4 * c] = t.x; f[4 * c + 1] = t.y; f[4 * c + 2] = t.z; f[4 * c + 3] = t.w;
+            }
+#pragma unroll
+            for (int i = 0; i < 32; ++i) { if (p.in_act) f[i] = f[i] / (1.0f + expf(-f[i])); amax = fmaxf(amax, fabsf(f[i])); }
+            const int e = mx_scale_e8m0(amax);
+            const float inv = mx_inv_scale(e), sc = __uint_as_float((uint32_t)e << 23);
+            float* dst = sx + (long)mi * p.K + kb * 32;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int w = (int)mx_pack4(f[4 * c] * inv, f[4 * c + 1] * inv, f[4 * c + 2] * inv, f[4 * c + 3] * inv);
+                const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(w, false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(w, true);
+                *(float4*)(dst + 4 * c) = make_float4(lo[0] * sc, lo[1] * sc, hi[0] * sc, hi[1] * sc);
+            }
+        }
+        __syncthreads();
+        // SKM_RG groups of 4 output rows per wave: the staged (and quantised) activation serves 64 rows of W per workgroup instead of 16
+        for (int rg = 0; rg < SKM_RG; ++rg) {
+        const int n0 = ((blockIdx.x * 4 + wave) * SKM_RG + rg) * 4;
+        if (n0 >= p.N) break;
+        float acc[4][4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) acc[r][mi] = 0.f;
+        const uint8_t* __restrict__ w8 = (const uint8_t*)p.W8;
+        for (int k = lane * 16; k < p.K; k += 64 * 16) {
+            uint4 wv[4]; uint32_t sd[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const bool ok = n0 + r < p.N;
+                wv[r] = ok ? *(const uint4*)(w8 + (long)(n0 + r) * p.K + k) : make_uint4(0, 0, 0, 0);
+                sd[r] = ok ? p.SW[(long)(k >> 7) * p.sw_ld + n0 + r] : 0u;
+            }
+            float xr[4][16];
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) xr[mi][e] = mi < mr ? sx[mi * p.K + k + e] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float sc = __uint_as_float(((sd[r] >> (8 * ((k >> 5) & 3))) & 0xffu) << 23);
+                const int wq[4] = {(int)wv[r].x, (int)wv[r].y, (int)wv[r].z, (int)wv[r].w};
+                float wf[16];               // the lane's 16 weights share one block: unscaled products first, the scale once per row and block
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const auto lo = __builtin_amdgcn_cvt_pk_f32_fp8(wq[c], false), hi = __builtin_amdgcn_cvt_pk_f32_fp8(wq[c], true);
+                    wf[4 * c] = lo[0]; wf[4 * c + 1] = lo[1]; wf[4 * c + 2] = hi[0]; wf[4 * c + 3] = hi[1];
+                }
+#pragma unroll
+                for (int mi = 0; mi < 4; ++mi) {
+                    if (mi < mr) {          // wave-uniform: only the live activation rows (Flux: one or two)
+                        float t = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 16; ++e) t = fmaf(xr[mi][e], wf[e], t);
+                        acc[r][mi] = fmaf(t, sc, acc[r][mi]);
+                    }
+                }
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi) {
+                const float v = wave_sum(acc[r][mi]);
+                const int m = mb + mi, n = n0 + r;
+                if (lane == 0 && mi < mr && n < p.N) {
+                    float o = v + (p.bias ? p.bias[n] : 0.f);
+                    if (p.out_act) o = o / (1.0f + expf(-o));
+                    if (p.accum) o += p.out[(long)m * p.ldo + n];
+                    p.out[(long)m * p.ldo + n] = o;
+                }
+            }
+        }
+    }
+}
+
 void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s) {
     if (a.M <= 0 || a.N <= 0) return;
     dim3 grid((a.N + 15) / 16), block(256);
     const size_t lds = (size_t)4 * a.K * sizeof(float);
+    if (a.W8 && (a.K & 31) == 0) {
+        static DevOnce once;
+        set_dyn_lds(once, (const void*)skinny_mx_kernel, 160 * 1024);
+        hipLaunchKernelGGL(skinny_mx_kernel, dim3((a.N + 16 * SKM_RG - 1) / (16 * SKM_RG)), block, lds, s, a);
+        return;
+    }
     if (dt == DT_BF16) {
         static DevOnce once;
     set_dyn_lds(once, (const void*)skinny_kernel<__bf16>, 160 * 1024);

@@ -120,6 +120,9 @@ struct SkinnyArgs {
     const float* x; int ldx; const void* W; const float* bias; float* out; int ldo;
     int M, N, K; int in_act; int out_act;
     int accum;                     // 1: out += result (sums the Flux time / guidance / vector embedders)
+    // W8 != null (K % 32 == 0): MX fp8 weights (e4m3 bytes [N][K], scales SW as GemmArgs::SW) and the activation MX fake-quantised while it is staged
+    // (Flux fp8 mode, round 6: the 77 adaLN modulation projections stream 3.2 GB of weights per forward instead of 6.4)
+    const void* W8; const uint32_t* SW; int sw_ld;
 };
 void launch_skinny(const SkinnyArgs& a, DType dt, hipStream_t s);
 

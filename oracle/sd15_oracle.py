@@ -966,7 +966,8 @@ def mx_attention(q, k, v, scale=None):
     return ((p8 @ vf.double()) / p8.sum(-1, keepdim=True)).float()          # the denominator sums the ROUNDED P (a ones row of V^T on the matrix pipe)
 
 
-_MX_LINEARS = ("_attn.qkv", "_attn.proj", "_mlp.0", "_mlp.2", ".linear1", ".linear2")
+# the linears of the build's MX fp8 mode: the block linears and (round 6) the adaLN modulation projections, which the engine runs as one batched skinny GEMM on MX weights
+_MX_LINEARS = ("_attn.qkv", "_attn.proj", "_mlp.0", "_mlp.2", ".linear1", ".linear2", "_mod.lin", ".modulation.lin", "final_layer.adaLN_modulation.1")
 
 
 def flux_forward(sd, cfg, x, timestep, context, y, guidance, fb=None, mx=False, mx_attn=None):
