@@ -598,8 +598,8 @@ class FluxEngine:
     """Flux3.forward behind BaseModel.apply_model with CONST prediction."""
 
     def __init__(self, cfg: FluxConfig, state_dict, device: int = 0, dtype: str = "bf16", fp8: bool = False):
-        """fp8=True (or "linears"): the block linears run on MX fp8 operands, attention in 16 bit (ldx_flux_set_fp8 mode 1; approximate, opt-in, own parity
-        class).  fp8="attn": explicit opt-in to the less precise full mode (mode 3): at head dim 128 QK^T / PV of the joint attention run on MX fp8 too."""
+        """fp8=True (or "linears"): the block linears (and the adaLN modulation projections) run on MX fp8 operands, attention in 16 bit (ldx_flux_set_fp8 mode 1;
+        approximate, opt-in, own parity class).  fp8="attn": explicit opt-in to the less precise full mode (mode 3): at head dim 128 QK^T / PV of the joint attention run on MX fp8 too."""
         self._lib = lib.load()
         self._h = C.c_void_p()
         self.cfg, self.device = cfg, torch.device("cuda", device)
