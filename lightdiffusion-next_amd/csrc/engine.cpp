@@ -639,6 +639,11 @@ bool Engine::op_rowgemm(const char* name, Act X, const LinearW& w, Act Y, Act R,
     a.X = ptr(X); a.ldx = X.ld; a.Y = ptr(Y); a.ldy = Y.ld; a.M = X.rows; a.N = w.N; a.K = w.K; a.W = w.w; a.bias = w.b;
     a.R = R.valid ? ptr(R) : nullptr; a.ldr = R.ld; a.pro = pro; a.eps = 1e-5f;
     if (nw) { a.g = nw->g; a.b = nw->b; }
+    // Round 6: with nothing to fuse in front (pro = 0: to_out / proj_out + residual) the kernel only competes with the plain tile GEMM, whose output stage went
+    // lean: at K = 640 and many rows (CFG batch 16: M = 65 536) the tile GEMM wins (92 against 156 us per launch); at bs = 1 (M = 8192) the two are level in the
+    // step (13.27 against 13.28 ms) and the row block stays.
+    static const long plain640_maxm = getenv("LDX_ROWGEMM_PLAIN640_MAXM") ? atol(getenv("LDX_ROWGEMM_PLAIN640_MAXM")) : 16384;
+    if (pro == 0 && a.K == 640 && a.M > plain640_maxm) return false;
     if (!w.w || !rowgemm_ok(a) || !rowblock_fills_chip((a.M + 128 * 320 / a.K - 1) / (128 * 320 / a.K) * (a.K / 320))) return false;
     Op o{}; o.kind = OP_ROWGEMM; o.name = name; o.rg = a;
     o.flops = 2.0 * a.M * (double)a.N * a.K;
