@@ -18,8 +18,17 @@ def _run(extra, env_extra=None, check=True):
         env.pop(k, None)
     env["OMP_NUM_THREADS"] = "1"
     env.update(env_extra or {})
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--stub-engine", "--latent", "8", "--steps", "3", "--warmup", "1",
-                        "--repeats", "2"] + extra, env=env, capture_output=True, text=True, timeout=300)
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--stub-engine", "--latent", "8", "--steps", "3", "--warmup", "1", "--repeats", "2"] + extra
+    p = None
+    for attempt in range(3):          # the self-launch picks a free rendezvous port and releases it before torchrun binds it: a lost race is retried, not reported
+        try:
+            p = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300)
+        except subprocess.TimeoutExpired:
+            if attempt == 2:
+                raise
+            continue
+        if p.returncode == 0 or not check or not any(t in p.stderr for t in ("Address already in use", "EADDRINUSE", "address already in use")):
+            break
     if check:
         assert p.returncode == 0, p.stderr[-2000:]
     return p

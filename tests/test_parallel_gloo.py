@@ -12,6 +12,37 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def _run_workers(target, world, args_of_rank, n_results, seconds=150, attempts=3):
+    """Spawn `world` worker processes on a fresh rendezvous port and collect `n_results` results.  A blocking SimpleQueue.get() waited forever when a worker died
+    before it could report (a rendezvous port taken between _free_port() and the store's bind: seen once per ~10 runs of the CPU suite in the build container), so
+    the wait is bounded and a silent attempt is repeated on another port; only `attempts` silent attempts in a row fail the test."""
+    import queue
+    ctx = mp.get_context("spawn")
+    codes = None
+    for _ in range(attempts):
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=target, args=(r, world, port) + tuple(args_of_rank(r, port)) + (q,)) for r in range(world)]
+        for p in procs:
+            p.start()
+        out = []
+        try:
+            for _i in range(n_results):
+                out.append(q.get(timeout=seconds))
+        except queue.Empty:
+            out = None
+        for p in procs:
+            p.join(timeout=30 if out is None else 120)
+            if p.is_alive():
+                p.terminate()
+                p.join(timeout=30)
+        codes = [p.exitcode for p in procs]
+        if out is not None:
+            assert all(c == 0 for c in codes), codes
+            return out
+    pytest.fail(f"no result from the worker processes in {attempts} attempts of {seconds} s (last exit codes {codes})")
+
+
 def _free_port():
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
@@ -51,16 +82,7 @@ def _worker(rank, world, port, total, q):
 @pytest.mark.parametrize("total", [4, 5])
 def test_batch_shard_matches_single_process(ldx, total):
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, total, q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    got = q.get()
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    got = _run_workers(_worker, world, lambda r, port: (total,), 1)[0]
     want = _toy_sample(ldx.parallel.shard_noise((total, 4, 8, 8), 42, 0, 1))
     assert got.shape == want.shape and torch.equal(got, want)
 
@@ -105,19 +127,10 @@ def test_shared_state_dict_equals_private_synthesis(ldx, tmp_path, usable):
     """Round 5 (multi-GPU start-up): one synthesis per node through a mapped file == every rank's own synth_state_dict, bit for bit; and when no
     directory can take the file (usable = False) every rank falls back to its own synthesis — nobody waits for a file that will not come."""
     world = 2
-    ctx = mp.get_context("spawn")
-    q = ctx.SimpleQueue()
-    port = _free_port()
     d = tmp_path / ("pub" if usable else "missing")
     if usable:
         d.mkdir()
-    procs = [ctx.Process(target=_sd_worker, args=(r, world, port, str(d), q)) for r in range(world)]
-    for p in procs:
-        p.start()
-    res = dict(q.get() for _ in procs)
-    for p in procs:
-        p.join(timeout=120)
-        assert p.exitcode == 0
+    res = dict(_run_workers(_sd_worker, world, lambda r, port: (str(d),), world))
     assert res == {0: True, 1: True}
     path = str(tmp_path / "sd.bin")
     with pytest.raises(RuntimeError):                                   # a file of another model is refused, not mis-mapped
