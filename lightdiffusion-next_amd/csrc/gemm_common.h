@@ -243,10 +243,15 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p_in, f32x4 (&acc)
     // together in front of its stores.  Same float operations in the same order per element.
     const int rpb = p.rows_per_batch > 0 ? p.rows_per_batch : 1;
     const int wrow0 = m0 + wm * (BM / WM), wcol0 = n0 + wn * (BN / 2) + 4 * g4;
-    // the lean path (gemm_epilogue_lean) and its residual prefetch
-    const bool lean = !LNF && (GNOK || BM == 256) && !p.ep_general && p.C && p.bias && !p.C8 && !p.geglu && p.act == 0 && p.oscale == 0.f && !p.R2 && !p.Cf && ((p.M | p.N) & 15) == 0 &&
-                      !((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) && !(MI * NJ > 20 && p.gn_partial) && (!p.R || (NR > 1 ? use_rpre : (MI * NJ <= 28 && (GNOK || BM == 256))));
-    constexpr bool RALL = !LNF && NR == 1 && MI * NJ <= 28 && (GNOK || BM == 256);       // (the register-staged MX kernels — GNOK false, BM < 256 — have no room: one spilled VGPR at 128 x 160)       // NR > 1: the caller already requested them ahead of its K loop (rpre).  256-wide tiles (128 accumulators + 64 residual registers) spill: their residual epilogues take the general stage
+    // The lean path (gemm_epilogue_lean) and its residual prefetch.  Who takes it: every epilogue made of bias [+ per-image vector] [* gate] [+ residual] [+ second
+    // store] [+ statistics] on whole 16 x 16 blocks whose tile lies in one image.  Who does not: LayerNorm-folded tiles (LNF), the register-staged MX kernels (GNOK
+    // false and BM < 256: their K loop leaves no register — one spilled VGPR at 128 x 160), GroupNorm-producing tiles wider than 160 columns (GNW below) and 256-wide
+    // tiles with a residual (128 accumulators + 64 residual registers spill).  Residual rows: NR > 1 = the caller requested them ahead of its K loop (rpre);
+    // otherwise (RALL) they are all requested here, at the top of the stage.
+    constexpr bool LEAN_OK = !LNF && (GNOK || BM == 256);
+    const bool lean = LEAN_OK && !p.ep_general && p.C && p.bias && !p.C8 && !p.geglu && p.act == 0 && p.oscale == 0.f && !p.R2 && !p.Cf && ((p.M | p.N) & 15) == 0 &&
+                      !((p.rowvec || p.gate) && m0 / rpb != (min(m0 + BM, p.M) - 1) / rpb) && !(MI * NJ > 20 && p.gn_partial) && (!p.R || (NR > 1 ? use_rpre : MI * NJ <= 28));
+    constexpr bool RALL = LEAN_OK && NR == 1 && MI * NJ <= 28;
     constexpr bool RANY = RALL || (!LNF && NR == MI * NJ);
     uint2 rall[RALL ? MI * NJ : 1];
     if constexpr (RALL) {
